@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Capture golden vectors G1-G6 from the *reference's own modules* (SURVEY.md section 8(c)).
+
+Runs ONLY in the build container, where /root/reference is mounted.  It imports the
+reference's ``network.xception``, ``network.vivit.module`` and ``network.vivit.vivit``
+(the last one needs a stand-in for ``network.models_copy``, whose third-party imports are
+absent), drives them with the closed-form tensors of ``recipe.py`` and stores only
+OUTPUTS (plus the config that produced them) as small ``.npz`` files next to this script.
+No reference source or bytecode is written anywhere.
+
+    python tests/golden/make_golden.py [--only G1,G5]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = os.environ.get('ISTVT_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+import recipe  # noqa: E402
+
+torch.set_num_threads(os.cpu_count() or 1)
+
+
+# --------------------------------------------------------------------------------------
+# reference imports (+ the one stub)
+# --------------------------------------------------------------------------------------
+import network.xception as ref_xception  # noqa: E402
+import network.vivit.module as ref_module  # noqa: E402
+
+
+class _XcepWrapper(nn.Module):
+    """Stand-in for reference TransferModel('xception') (models_copy.py:34-45, 233-234):
+    `.model` is the Xception with `last_linear = Sequential(Dropout, Linear(2048, n))`."""
+
+    def __init__(self, num_out_classes):
+        super().__init__()
+        self.model = ref_xception.return_pytorch04_xception(pretrained=False)
+        num_ftrs = self.model.last_linear.in_features
+        self.model.last_linear = nn.Sequential(nn.Dropout(p=0.5), nn.Linear(num_ftrs, num_out_classes))
+
+    def low_level_features(self, x):
+        return self.model.low_level_features(x)
+
+
+def _stub_model_selection(modelname, num_out_classes, dropout=None, batch_size=16):
+    assert modelname == 'xception'
+    return _XcepWrapper(num_out_classes)
+
+
+_stub = types.ModuleType('network.models_copy')
+_stub.model_selection = _stub_model_selection
+sys.modules['network.models_copy'] = _stub
+import network.vivit.vivit as ref_vivit  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------
+def load_recipe(module: nn.Module, prefix: str = ''):
+    sd = module.state_dict()
+    vals = recipe.fill_state_dict(sd, prefix)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+
+
+def t(a):
+    return torch.from_numpy(a)
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+# --------------------------------------------------------------------------------------
+def g1_stem():
+    out = {}
+    for side in (96, 139):
+        net = ref_xception.xception(pretrained=False)
+        load_recipe(net, 'xcep.model.')
+        net.train()
+        x = t(recipe.input_value('g1.x%d' % side, (2, 3, side, side))).requires_grad_(True)
+        y = net.low_level_features(x)
+        coef = t(recipe.input_value('g1.coef%d' % side, tuple(y.shape)))
+        (y * coef).sum().backward()
+        tag = 's%d.' % side
+        out[tag + 'y'] = npy(y)
+        out[tag + 'dx_norm'] = npy(x.grad.norm())
+        out[tag + 'dx_slice'] = npy(x.grad[0, :, 10:14, 20:28])
+        sd = net.state_dict()
+        for k in ('bn1', 'bn2', 'block1.skipbn', 'block2.rep.2', 'block3.rep.5', 'block3.skipbn'):
+            out[tag + k + '.running_mean'] = npy(sd[k + '.running_mean'])
+            out[tag + k + '.running_var'] = npy(sd[k + '.running_var'])
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+        for k in ('conv1.weight', 'conv2.weight', 'block1.rep.0.conv1.weight', 'block2.rep.4.conv1.weight',
+                  'block3.skip.weight', 'block3.rep.5.weight', 'block3.rep.5.bias', 'bn1.weight',
+                  'block2.rep.1.pointwise.weight'):
+            g = dict(net.named_parameters())[k].grad
+            out[tag + 'grad.' + k] = npy(g.reshape(-1)[:4096])
+    save('G1_stem', **out)
+
+
+MOD_CFG = dict(dim=64, heads=2, dim_head=32)
+ROW_STRIDE = {5: 3, 9: 7}
+
+
+def _run_module(mod, x_name, shape):
+    x = t(recipe.input_value(x_name, shape)).requires_grad_(True)
+    y = mod(x)
+    coef = t(recipe.input_value(x_name + '.coef', tuple(y.shape)))
+    (y * coef).sum().backward()
+    res = {'y': npy(y), 'dx': npy(x.grad)}
+    for k, p in mod.named_parameters():
+        res['grad.' + k] = npy(p.grad)
+    return res
+
+
+def g2_modules():
+    out = {}
+    dim, heads, dh = MOD_CFG['dim'], MOD_CFG['heads'], MOD_CFG['dim_head']
+    for F in (5, 9):
+        shape = (1, F * 362, dim)
+        mods = {
+            'prenorm_ff': ref_module.PreNorm(dim, ref_module.FeedForward(dim, 4 * dim)),
+            'ff': ref_module.FeedForward(dim, 4 * dim),
+            'spatial': ref_module.SpatialOnlyAttention(dim, heads=heads, dim_head=dh),
+            'temporal': ref_module.TemporalResidualAttention(dim, heads=heads, dim_head=dh),
+        }
+        for name, mod in mods.items():
+            load_recipe(mod, 'g2.%s.' % name)
+            res = _run_module(mod, 'g2.%s.F%d' % (name, F), shape)
+            for k, v in res.items():
+                if k in ('y', 'dx'):      # row subsample keeps the fixture small
+                    v = v[:, ::ROW_STRIDE[F]]
+                out['F%d.%s.%s' % (F, name, k)] = v
+    save('G2_modules', **out)
+
+
+def g3_layer():
+    dim, heads, dh = MOD_CFG['dim'], MOD_CFG['heads'], MOD_CFG['dim_head']
+    mod = ref_vivit.STTransformer(dim, 2, heads, dh, 2 * dim)
+    load_recipe(mod, 'g3.')
+    res = _run_module(mod, 'g3.x', (1, 5 * 362, dim))
+    res['y'] = res['y'][:, ::3]
+    res['dx'] = res['dx'][:, ::3]
+    save('G3_sttransformer', **res)
+
+
+def g4_dsttr():
+    out = {}
+    dim, heads, dh = MOD_CFG['dim'], MOD_CFG['heads'], MOD_CFG['dim_head']
+    for T in (4, 8):
+        mod = ref_vivit.DSTTr(19, 1, 1, T, dim=dim, depth=2, heads=heads, dim_head=dh, in_channels=dim, scale_dim=2)
+        load_recipe(mod, 'g4.')
+        x = t(recipe.input_value('g4.x.T%d' % T, (2, T, dim, 19, 19))).requires_grad_(True)
+        y = mod(x)
+        coef = t(recipe.input_value('g4.coef', tuple(y.shape)))
+        (y * coef).sum().backward()
+        tag = 'T%d.' % T
+        out[tag + 'logits'] = npy(y)
+        out[tag + 'dx_norm'] = npy(x.grad.norm())
+        out[tag + 'dx_frame_norms'] = npy(x.grad.flatten(2).norm(dim=2))
+        for k, p in mod.named_parameters():
+            out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+        out[tag + 'grad.pos_embedding'] = npy(mod.pos_embedding.grad[0, :, ::37])
+        out[tag + 'grad.space_token'] = npy(mod.space_token.grad)
+        out[tag + 'grad.temporal_token'] = npy(mod.temporal_token.grad)
+    save('G4_dsttr', **out)
+
+
+def g5_end_to_end():
+    """Reference-native geometry: XceptionVidTr() on (1,6,3,300,300), BCE vs label 1, one SGD step."""
+    model = ref_vivit.XceptionVidTr()
+    load_recipe(model, '')
+    model.train()
+    x = t(recipe.input_value('g5.x', (1, 6, 3, 300, 300)))
+    labels = torch.ones(1)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=0)
+    opt.zero_grad()
+    logits = model(x)
+    loss = nn.BCEWithLogitsLoss()(logits.view(-1), labels.float())
+    loss.backward()
+    out = {'logits': npy(logits), 'loss': npy(loss)}
+    names = []
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            out['gnorm.' + k] = npy(p.grad.norm())
+    out['live_param_names'] = np.array(names)
+    slice_names = ['vit.transformer.layers.0.0.fn.to_qk.weight', 'vit.transformer.layers.11.2.fn.net.3.weight',
+                   'vit.transformer.layers.5.1.fn.to_qkv.weight', 'vit.pos_embedding', 'xcep.model.conv1.weight',
+                   'xcep.model.block3.rep.4.pointwise.weight']
+    named = dict(model.named_parameters())
+    for k in slice_names:
+        out['grad.' + k] = npy(named[k].grad.reshape(-1)[:64])
+    opt.step()
+    for k in slice_names:
+        out['after_sgd.' + k] = npy(named[k].reshape(-1)[:64])
+    sd = model.state_dict()
+    out['bn1.running_mean'] = npy(sd['xcep.model.bn1.running_mean'])
+    out['bn1.running_var'] = npy(sd['xcep.model.bn1.running_var'])
+    save('G5_native', **out)
+
+
+def g6_fullwidth():
+    mod = ref_vivit.DSTTr(19, 1, 1, 8, depth=2)
+    load_recipe(mod, 'vit.')
+    x = t(recipe.input_value('g6.x', (1, 8, 728, 19, 19))).requires_grad_(True)
+    y = mod(x)
+    y.sum().backward()
+    out = {'logits': npy(y), 'dx_norm': npy(x.grad.norm()), 'dx_frame_norms': npy(x.grad.flatten(2).norm(dim=2))}
+    for k, p in mod.named_parameters():
+        out['gnorm.' + k] = npy(p.grad.norm())
+    out['grad.qk0'] = npy(dict(mod.named_parameters())['transformer.layers.0.0.fn.to_qk.weight'].grad.reshape(-1)[:256])
+    save('G6_fullwidth', **out)
+
+
+ALL = {'G1': g1_stem, 'G2': g2_modules, 'G3': g3_layer, 'G4': g4_dsttr, 'G5': g5_end_to_end, 'G6': g6_fullwidth}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    todo = [s for s in a.only.split(',') if s] or list(ALL)
+    for k in todo:
+        print('==', k)
+        ALL[k]()
