@@ -1,0 +1,69 @@
+"""ctypes binding of libistvt_hip.so (C ABI declared in include/istvt_hip.h).
+
+There is no fallback: if the library is missing or a symbol is absent, importing the ops
+raises.  Build with ``python 2023-tifs-istvt_amd/build.py`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libistvt_hip.so')
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+# name -> argtypes (all return int).  Mirrors include/istvt_hip.h one to one.
+SIGNATURES = {
+    'istvt_gemm': [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, I, I, I, F, I, P],
+    'istvt_layernorm_fwd': [P, P, P, P, P, P, L, I, F, I, P],
+    'istvt_layernorm_fwd_diff': [P, P, P, P, P, P, P, I, I, I, I, F, I, P],
+    'istvt_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
+    'istvt_attn_spatial_fwd': [P, P, P, I, I, I, I, F, I, P],
+    'istvt_attn_spatial_bwd': [P, P, P, P, P, P, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_fwd': [P, P, P, P, I, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
+    'istvt_tokens_fwd': [P, P, P, P, P, I, I, I, I, I, I, P],
+    'istvt_tokens_bwd': [P, P, P, P, P, I, I, I, I, I, I, P],
+    'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],
+    'istvt_colsum': [P, P, L, I, L, I, P],
+    'istvt_cast': [P, I, P, I, L, P],
+}
+
+_lib = None
+
+
+class IstvtLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IstvtLibraryError(
+                'libistvt_hip.so not found at %s: build it with `python 2023-tifs-istvt_amd/build.py`; '
+                'there is no CPU or PyTorch fallback for the ISTVT hot path' % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:
+                raise IstvtLibraryError('libistvt_hip.so lacks symbol %s (stale build?)' % name) from e
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc == -2:
+        msg = 'unsupported dtype'
+    elif rc == -3:
+        msg = 'invalid shape/argument'
+    elif rc <= -1000:
+        msg = 'hipError_t %d at launch' % (-rc - 1000)
+    else:
+        msg = 'error %d' % rc
+    raise RuntimeError('%s failed: %s' % (what, msg))

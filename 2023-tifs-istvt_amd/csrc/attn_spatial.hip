@@ -1,0 +1,446 @@
+// Fused per-frame spatial self-attention (reference: SpatialOnlyAttention.forward,
+// network/vivit/module.py:81-93): for every (clip b, frame f, head h)
+//     O = softmax(Q K^T * DH^-1/2) V        Q,K,V: [P tokens][DH]
+// read straight out of the packed projection buffer qkv[M][3*inner] (q | k | v, heads h-major
+// inside each third: 'b n (h d)'), written as out[M][inner]; scores never leave registers.
+//
+// MFMA formulation (16x16 tiles, K=32 logical steps, see common.h):
+//   S^T = K Q^T      keys on accumulator rows, queries on lanes  (A = K rows from LDS,
+//                    B = Q rows held in registers)
+//   softmax over keys = in-lane over the tile registers + 2 cross-lane-group shuffles
+//   O^T = V^T P^T    the S^T accumulators ARE the B operand (k-slot (g,j) <-> key
+//                    32s + 16(j>>2) + 4g + (j&3)); A = V read transposed from its row-major LDS
+//                    image (ds_read_b64_tr_b16 for bf16).
+// One wavefront owns 32 queries for the whole kernel; the 4 wavefronts of a workgroup share the
+// K/V images; keys stream through LDS in chunks of 128 with online-softmax rescaling, so any P
+// works (197 -> 2 chunks, 362 -> 3).
+//
+// Backward = two kernels that recompute P from the saved log-sum-exp:
+//   sattn_bwd_dq : same geometry as forward; dS^T = P^T o (dP^T - delta) ; dQ^T += K^T dS^T
+//   sattn_bwd_dkv: one wavefront owns 32 keys; queries stream through LDS;
+//                  dV^T += dO^T P ; dK^T += Q^T dS
+#include "common.h"
+
+constexpr int CHUNK = 128;          // rows of an LDS image
+constexpr int NT = CHUNK / 16;      // 16-row tiles per chunk
+constexpr int IPAD = 8;             // row padding (elements)
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// copy rows [row0, row0+CHUNK) x DH columns of a [rows][ld] matrix into an LDS image, zero-filling
+// rows >= nrows
+template <typename T, int DH>
+__device__ __forceinline__ void stage_img(T* img, const T* __restrict__ src, long ld, int row0, int nrows, int tid) {
+    constexpr int LDI = DH + IPAD;
+    constexpr int VPR = DH / 8;
+    constexpr int NV = CHUNK * VPR / 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 256 * i;
+        const int row = v / VPR, col = (v % VPR) * 8;
+        typename Mma<T>::frag f;
+        if (row0 + row < nrows) f = frag_load(src + (long)(row0 + row) * ld + col);
+        else f = Mma<T>::zero();
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<bf16x8*>(img + row * LDI + col) = f;
+        } else {
+            float* p = (float*)(img + row * LDI + col);
+            *reinterpret_cast<float4*>(p) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+        }
+    }
+}
+
+// fragment (8 consecutive d) of one row of a global matrix, zero if the row is out of range
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::frag row_frag(const T* __restrict__ src, long ld, int row, int nrows,
+                                                           int col) {
+    if (row < nrows) return frag_load(src + (long)row * ld + col);
+    return Mma<T>::zero();
+}
+
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::frag acc_frag(const f32x4& lo, const f32x4& hi) {
+    typename Mma<T>::frag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { Mma<T>::set(f, i, lo[i]); Mma<T>::set(f, 4 + i, hi[i]); }
+    return f;
+}
+
+__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same r)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                        float* __restrict__ lse, int P, int heads, float scale) {
+    constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
+    T* Kimg = smem;
+    T* Vimg = smem + CHUNK * LDI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
+    const int inner = heads * DH;
+    const long ld = 3L * inner;
+    const T* base = qkv + (long)bf * P * ld;
+    const T* qp = base + h * DH;
+    const T* kp = base + inner + h * DH;
+    const T* vp = base + 2 * inner + h * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < P;
+    const float c = scale * LOG2E;
+
+    typename Mma<T>::frag qf[2][KS];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[u][ks] = row_frag<T>(qp, ld, q0 + 16 * u + r, P, 32 * ks + 8 * g);
+
+    f32x4 o[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4{0, 0, 0, 0}; o[dt][1] = f32x4{0, 0, 0, 0}; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    for (int c0 = 0; c0 < P; c0 += CHUNK) {
+        if (c0) __syncthreads();
+        stage_img<T, DH>(Kimg, kp, ld, c0, P, tid);
+        stage_img<T, DH>(Vimg, vp, ld, c0, P, tid);
+        __syncthreads();
+        if (!active) continue;
+        f32x4 s[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s[t][0] = f32x4{0, 0, 0, 0}; s[t][1] = f32x4{0, 0, 0, 0};
+            if (c0 + 16 * t < P) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    typename Mma<T>::frag kf = frag_load(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
+                    Mma<T>::mma(s[t][0], kf, qf[0][ks]);
+                    Mma<T>::mma(s[t][1], kf, qf[1][ks]);
+                }
+            }
+        }
+        // online softmax in the log2 domain; lane owns query r of sub-tile u, keys 4g+j of each tile
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = c0 + 16 * t + 4 * g + j;
+                    const float z = key < P ? s[t][u][j] * c : -INFINITY;
+                    s[t][u][j] = z;
+                    mx = fmaxf(mx, z);
+                }
+            mx = group_max(mx);
+            const float m_new = fmaxf(m_run[u], mx);
+            const float alpha = fast_exp2(m_run[u] - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float pv = fast_exp2(s[t][u][j] - m_new);
+                    s[t][u][j] = pv;
+                    sum += pv;
+                }
+            sum = group_sum(sum);
+            l_run[u] = l_run[u] * alpha + sum;
+            m_run[u] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt][u] *= alpha;
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int ss = 0; ss < NT / 2; ++ss) {
+            if (c0 + 32 * ss < P) {
+                typename Mma<T>::frag p0 = acc_frag<T>(s[2 * ss][0], s[2 * ss + 1][0]);
+                typename Mma<T>::frag p1 = acc_frag<T>(s[2 * ss][1], s[2 * ss + 1][1]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    typename Mma<T>::frag vf =
+                        frag_load_tr(Vimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                    Mma<T>::mma(o[dt][0], vf, p0);
+                    Mma<T>::mma(o[dt][1], vf, p1);
+                }
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = q0 + 16 * u + r;
+        if (q >= P) continue;
+        const float inv = 1.0f / l_run[u];
+        T* op = out + ((long)bf * P + q) * inner + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float v[4] = {o[dt][u][0] * inv, o[dt][u][1] * inv, o[dt][u][2] * inv, o[dt][u][3] * inv};
+            store4(op + 16 * dt + 4 * g, v);
+        }
+        if (g == 0) lse[((long)bf * P + q) * heads + h] = (m_run[u] + log2f(l_run[u])) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward part 1: delta = rowsum(dO o O), dQ
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                           const T* __restrict__ dout, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, T* __restrict__ dqkv, int P,
+                                                           int heads, float scale) {
+    constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
+    T* Kimg = smem;
+    T* Vimg = smem + CHUNK * LDI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
+    const int inner = heads * DH;
+    const long ld = 3L * inner;
+    const T* base = qkv + (long)bf * P * ld;
+    const T* qp = base + h * DH;
+    const T* kp = base + inner + h * DH;
+    const T* vp = base + 2 * inner + h * DH;
+    const T* op = out + (long)bf * P * inner + h * DH;
+    const T* dop = dout + (long)bf * P * inner + h * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool active = q0 < P;
+    const float c = scale * LOG2E;
+
+    typename Mma<T>::frag qf[2][KS], dof[2][KS];
+    float lq[2], dl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = q0 + 16 * u + r;
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[u][ks] = row_frag<T>(qp, ld, q, P, 32 * ks + 8 * g);
+            dof[u][ks] = row_frag<T>(dop, inner, q, P, 32 * ks + 8 * g);
+            if (q < P) {
+                float a[8], b[8];
+                load8(dop + (long)q * inner + 32 * ks + 8 * g, a);
+                load8(op + (long)q * inner + 32 * ks + 8 * g, b);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) part += a[i] * b[i];
+            }
+        }
+        dl[u] = group_sum(part);
+        lq[u] = q < P ? lse[((long)bf * P + q) * heads + h] * LOG2E : 0.f;
+        if (q < P && g == 0) delta[((long)bf * P + q) * heads + h] = dl[u];
+    }
+
+    f32x4 dq[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0, 0, 0, 0}; dq[dt][1] = f32x4{0, 0, 0, 0}; }
+
+    for (int c0 = 0; c0 < P; c0 += CHUNK) {
+        if (c0) __syncthreads();
+        stage_img<T, DH>(Kimg, kp, ld, c0, P, tid);
+        stage_img<T, DH>(Vimg, vp, ld, c0, P, tid);
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int ss = 0; ss < NT / 2; ++ss) {
+            if (c0 + 32 * ss >= P) continue;
+            f32x4 s[2][2], dp[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                s[tt][0] = f32x4{0, 0, 0, 0}; s[tt][1] = f32x4{0, 0, 0, 0};
+                dp[tt][0] = f32x4{0, 0, 0, 0}; dp[tt][1] = f32x4{0, 0, 0, 0};
+                const int krow = 32 * ss + 16 * tt + r;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    typename Mma<T>::frag kf = frag_load(Kimg + krow * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag vf = frag_load(Vimg + krow * LDI + 32 * ks + 8 * g);
+                    Mma<T>::mma(s[tt][0], kf, qf[0][ks]);
+                    Mma<T>::mma(s[tt][1], kf, qf[1][ks]);
+                    Mma<T>::mma(dp[tt][0], vf, dof[0][ks]);
+                    Mma<T>::mma(dp[tt][1], vf, dof[1][ks]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = c0 + 32 * ss + 16 * tt + 4 * g + j;
+                        const float pv = key < P ? fast_exp2(s[tt][u][j] * c - lq[u]) : 0.f;
+                        s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]) * scale;       // dS^T
+                    }
+            }
+            typename Mma<T>::frag ds0 = acc_frag<T>(s[0][0], s[1][0]);
+            typename Mma<T>::frag ds1 = acc_frag<T>(s[0][1], s[1][1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                typename Mma<T>::frag kt = frag_load_tr(Kimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                Mma<T>::mma(dq[dt][0], kt, ds0);
+                Mma<T>::mma(dq[dt][1], kt, ds1);
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = q0 + 16 * u + r;
+        if (q >= P) continue;
+        T* dqp = dqkv + ((long)bf * P + q) * ld + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float v[4] = {dq[dt][u][0], dq[dt][u][1], dq[dt][u][2], dq[dt][u][3]};
+            store4(dqp + 16 * dt + 4 * g, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward part 2: dK, dV.  Wave owns 32 keys; queries stream through LDS.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                            int P, int heads, float scale) {
+    constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
+    __shared__ __attribute__((aligned(16))) float stat[2][CHUNK];
+    T* Qimg = smem;
+    T* Dimg = smem + CHUNK * LDI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
+    const int inner = heads * DH;
+    const long ld = 3L * inner;
+    const T* base = qkv + (long)bf * P * ld;
+    const T* qp = base + h * DH;
+    const T* kp = base + inner + h * DH;
+    const T* vp = base + 2 * inner + h * DH;
+    const T* dop = dout + (long)bf * P * inner + h * DH;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const bool active = k0 < P;
+    const float c = scale * LOG2E;
+
+    typename Mma<T>::frag kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[kt][ks] = row_frag<T>(kp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
+            vf[kt][ks] = row_frag<T>(vp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
+        }
+    f32x4 dk[DT][2], dv[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        dk[dt][0] = f32x4{0, 0, 0, 0}; dk[dt][1] = f32x4{0, 0, 0, 0};
+        dv[dt][0] = f32x4{0, 0, 0, 0}; dv[dt][1] = f32x4{0, 0, 0, 0};
+    }
+
+    for (int c0 = 0; c0 < P; c0 += CHUNK) {
+        if (c0) __syncthreads();
+        stage_img<T, DH>(Qimg, qp, ld, c0, P, tid);
+        stage_img<T, DH>(Dimg, dop, inner, c0, P, tid);
+        if (tid < CHUNK) {
+            const int q = c0 + tid;
+            stat[0][tid] = q < P ? lse[((long)bf * P + q) * heads + h] * LOG2E : INFINITY;
+            stat[1][tid] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
+        }
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int ss = 0; ss < NT / 2; ++ss) {
+            if (c0 + 32 * ss >= P) continue;
+            f32x4 s[2][2], dp[2][2];      // [query tile tt][key tile kt]; rows = queries 4g+j, cols = keys r
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                s[tt][0] = f32x4{0, 0, 0, 0}; s[tt][1] = f32x4{0, 0, 0, 0};
+                dp[tt][0] = f32x4{0, 0, 0, 0}; dp[tt][1] = f32x4{0, 0, 0, 0};
+                const int qrow = 32 * ss + 16 * tt + r;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    typename Mma<T>::frag qa = frag_load(Qimg + qrow * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag da = frag_load(Dimg + qrow * LDI + 32 * ks + 8 * g);
+                    Mma<T>::mma(s[tt][0], qa, kf[0][ks]);
+                    Mma<T>::mma(s[tt][1], qa, kf[1][ks]);
+                    Mma<T>::mma(dp[tt][0], da, vf[0][ks]);
+                    Mma<T>::mma(dp[tt][1], da, vf[1][ks]);
+                }
+                const int qb = 32 * ss + 16 * tt + 4 * g;
+                const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][qb]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][qb]);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pv = fast_exp2(s[tt][kt][j] * c - lv[j]);
+                        s[tt][kt][j] = pv;                                         // P
+                        dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]) * scale;     // dS
+                    }
+            }
+            typename Mma<T>::frag p0 = acc_frag<T>(s[0][0], s[1][0]);
+            typename Mma<T>::frag p1 = acc_frag<T>(s[0][1], s[1][1]);
+            typename Mma<T>::frag ds0 = acc_frag<T>(dp[0][0], dp[1][0]);
+            typename Mma<T>::frag ds1 = acc_frag<T>(dp[0][1], dp[1][1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                typename Mma<T>::frag dot_ = frag_load_tr(Dimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                typename Mma<T>::frag qt_ = frag_load_tr(Qimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                Mma<T>::mma(dv[dt][0], dot_, p0);
+                Mma<T>::mma(dv[dt][1], dot_, p1);
+                Mma<T>::mma(dk[dt][0], qt_, ds0);
+                Mma<T>::mma(dk[dt][1], qt_, ds1);
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = k0 + 16 * kt + r;
+        if (key >= P) continue;
+        T* dkp = dqkv + ((long)bf * P + key) * ld + inner + h * DH;
+        T* dvp = dqkv + ((long)bf * P + key) * ld + 2 * inner + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            float a[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
+            float b[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            store4(dkp + 16 * dt + 4 * g, a);
+            store4(dvp + 16 * dt + 4 * g, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+#define DISPATCH_DH(DHV, ...)                                   \
+    do {                                                        \
+        if ((DHV) == 64) { constexpr int DH = 64; __VA_ARGS__; } \
+        else if ((DHV) == 32) { constexpr int DH = 32; __VA_ARGS__; } \
+        else return ISTVT_ERR_SHAPE;                            \
+    } while (0)
+
+// qkv: [BF*P][3*heads*dh]; out: [BF*P][heads*dh]; lse: [BF*P][heads] (natural log)
+extern "C" int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh,
+                                      float scale, int dtype, hipStream_t stream) {
+    if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    dim3 grid((P + 127) / 128, BF * heads), block(256);
+    DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<T, DH>), grid, block, 0, stream,
+                                                             (const T*)qkv, (T*)out, lse, P, heads, scale)));
+    return istvt_check_launch();
+}
+
+// delta: scratch [BF*P][heads] fp32 (written here, consumed by the dK/dV kernel); dqkv: [BF*P][3*inner]
+extern "C" int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                                      float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale,
+                                      int dtype, hipStream_t stream) {
+    if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    dim3 grid((P + 127) / 128, BF * heads), block(256);
+    DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, {
+        hipLaunchKernelGGL((sattn_bwd_dq_kernel<T, DH>), grid, block, 0, stream, (const T*)qkv, (const T*)out,
+                           (const T*)dout, lse, delta, (T*)dqkv, P, heads, scale);
+        hipLaunchKernelGGL((sattn_bwd_dkv_kernel<T, DH>), grid, block, 0, stream, (const T*)qkv, (const T*)dout, lse,
+                           (const float*)delta, (T*)dqkv, P, heads, scale);
+    }));
+    return istvt_check_launch();
+}

@@ -1,0 +1,170 @@
+// Shared device helpers for the ISTVT gfx950 (CDNA4) kernels.
+// Conventions used across csrc/:
+//   * storage dtype T is float (parity mode) or bf16_t (throughput mode); all arithmetic,
+//     statistics and accumulation are fp32.
+//   * a wavefront is 64 lanes; lane = threadIdx.x & 63; MFMA lane groups g = lane >> 4, r = lane & 15.
+//   * "fragment" = the 8 consecutive reduction-dim elements k = 8g .. 8g+7 one lane feeds to
+//     one logical K=32 MFMA step (bf16: one v_mfma_f32_16x16x32_bf16; f32: eight
+//     v_mfma_f32_16x16x4_f32 in which lane group g supplies element 8g+i in step i).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define ISTVT_OK 0
+#define ISTVT_ERR_DTYPE (-2)
+#define ISTVT_ERR_SHAPE (-3)
+#define ISTVT_ERR_LAUNCH (-4)
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+#define WAVE 64
+
+static inline int istvt_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ISTVT_OK : -(1000 + (int)e);
+}
+
+#define DISPATCH_DTYPE(dtype, ...)                         \
+    do {                                                   \
+        if ((dtype) == DT_F32) { typedef float T; __VA_ARGS__; }       \
+        else if ((dtype) == DT_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+        else return ISTVT_ERR_DTYPE;                       \
+    } while (0)
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---- 8-element chunks (16 B of bf16, 32 B of f32); p must be 16-byte aligned -------------
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+// ---- 4-element chunks (8 B of bf16, 16 B of f32) -------------------------------------------
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+}
+
+// ---- wave-level reductions (all 64 lanes get the result) ---------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- MFMA traits: one logical K=32 step on a 16x16 tile ----------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ void mma(f32x4& c, const frag& a, const frag& b) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag zero() {
+        frag f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (bf16_t)0.0f;
+        return f;
+    }
+    static __device__ __forceinline__ void set(frag& f, int i, float v) { f[i] = (bf16_t)v; }
+};
+struct f32frag { float v[8]; };
+template <> struct Mma<float> {
+    typedef f32frag frag;
+    static __device__ __forceinline__ void mma(f32x4& c, const frag& a, const frag& b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[i], b.v[i], c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag zero() {
+        frag f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.v[i] = 0.f;
+        return f;
+    }
+    static __device__ __forceinline__ void set(frag& f, int i, float v) { f.v[i] = v; }
+};
+
+// fragment from 8 contiguous elements in LDS/global (16-byte aligned)
+__device__ __forceinline__ bf16x8 frag_load(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ f32frag frag_load(const float* p) {
+    f32frag f;
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    return f;
+}
+
+// Transposed fragment: element i = img[(k0 + i) * ld + col], i.e. the reduction index runs
+// over ROWS of a row-major LDS image (ld in elements).  k0 must be a multiple of 4 and, for
+// bf16, `col16` (the first of the 16 columns this lane group covers) a multiple of 4.
+//   bf16: two ds_read_b64_tr_b16 (each: 4 rows x 16 cols block, lane i of the 16-lane group
+//         receives column i of the 4 rows); lane 4q+p supplies row q, cols 4p..4p+3.
+//   f32 : eight ds_read_b32.
+// k0a / k0b are the first rows of the two 4-row halves (elements 0..3 and 4..7).
+__device__ __forceinline__ bf16x8 frag_load_tr(const bf16_t* img, int ld, int k0a, int k0b, int col16, int r) {
+    const int q = r >> 2, p = r & 3;
+    typedef short4v __attribute__((address_space(3))) * lds_ptr;
+    const bf16_t* pa = img + (size_t)(k0a + q) * ld + col16 + 4 * p;
+    const bf16_t* pb = img + (size_t)(k0b + q) * ld + col16 + 4 * p;
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pb));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    short8v s;
+    s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3]; s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, s);
+}
+__device__ __forceinline__ f32frag frag_load_tr(const float* img, int ld, int k0a, int k0b, int col16, int r) {
+    f32frag f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f.v[i] = img[(size_t)(k0a + i) * ld + col16 + r];
+        f.v[4 + i] = img[(size_t)(k0b + i) * ld + col16 + r];
+    }
+    return f;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

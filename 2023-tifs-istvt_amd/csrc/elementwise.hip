@@ -1,0 +1,202 @@
+// Small HBM-bound helpers of the transformer path: column sums (bias gradients), token
+// assembly (reference DSTTr.forward, network/vivit/vivit.py:133-142) and dtype casts.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// out[n] += sum_m x[m][n]   (bias gradient of a Linear: colsum of dY).  fp32 accumulate, one
+// atomic per column per block.  Thread owns 8 consecutive columns; 4 waves split the rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N,
+                                                     long ld, int rows_per_block) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + lane * 8;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (col < N) {
+        for (long m = r0 + wid; m < r1; m += 4) {
+            float v[8];
+            load8(x + m * ld + col, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wid][lane * 8 + i] = acc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int gc = blockIdx.x * 512 + c;
+        if (gc < N) atomicAdd(out + gc, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
+}
+
+extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0) return ISTVT_ERR_SHAPE;
+    int rpb = (int)((M + 255) / 256);
+    if (rpb < 64) rpb = 64;
+    dim3 grid((N + 511) / 512, (unsigned)((M + rpb - 1) / rpb)), block(256);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)x, out, M, N, ld, rpb));
+    return istvt_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Token assembly.  feats [B][T][hw][D] (the stem's NHWC output IS this layout), P = hw + 1,
+// F = T + 1, x [B][F][P][D]:
+//   x[b,0,p]       = temporal_token                          (vivit.py:139-140, no pos-emb)
+//   x[b,1+t,0]     = space_token + pos[t][0]                 (vivit.py:136-138)
+//   x[b,1+t,1+i]   = feats[b,t,i] + pos[t][1+i]
+// pos is the parameter's leading [T][P] slice with row stride pos_ld (>= P) rows per frame.
+template <typename T>
+__global__ __launch_bounds__(128) void tokens_fwd_kernel(const T* __restrict__ feats, const float* __restrict__ space,
+                                                         const float* __restrict__ temporal,
+                                                         const float* __restrict__ pos, T* __restrict__ x, int B,
+                                                         int F, int P, int D, int pos_rows) {
+    const long row = blockIdx.x;                 // over B*F*P
+    const int p = (int)(row % P);
+    const int f = (int)((row / P) % F);
+    const long b = row / ((long)P * F);
+    const int hw = P - 1, Tn = F - 1;
+    for (int e = threadIdx.x * 8; e < D; e += 128 * 8) {
+        float o[8];
+        if (f == 0) {
+            load8(temporal + e, o);
+        } else {
+            float pe[8];
+            load8(pos + ((long)(f - 1) * pos_rows + p) * D + e, pe);
+            if (p == 0) load8(space + e, o);
+            else load8(feats + (((b * Tn + (f - 1)) * hw) + (p - 1)) * D + e, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += pe[i];
+        }
+        store8(x + row * D + e, o);
+    }
+}
+
+// backward of the assembly.  grid (P, F); loops over b.
+//   dfeats[b,t,i] = dx[b,1+t,1+i];  dpos[t][p] += sum_b dx[b,1+t,p];
+//   dspace += sum_{b,t} dx[b,1+t,0];  dtemporal += sum_{b,p} dx[b,0,p]
+template <typename T>
+__global__ __launch_bounds__(128) void tokens_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dfeats,
+                                                         float* __restrict__ dspace, float* __restrict__ dtemporal,
+                                                         float* __restrict__ dpos, int B, int F, int P, int D,
+                                                         int pos_rows) {
+    const int p = blockIdx.x, f = blockIdx.y;
+    const int hw = P - 1, Tn = F - 1;
+    for (int e = threadIdx.x * 8; e < D; e += 128 * 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long b = 0; b < B; ++b) {
+            float v[8];
+            load8(dx + ((b * F + f) * P + p) * D + e, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+            if (f > 0 && p > 0 && dfeats) store8(dfeats + (((b * Tn + (f - 1)) * hw) + (p - 1)) * D + e, v);
+        }
+        if (f == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(dtemporal + e + i, acc[i]);
+        } else {
+            float* dp = dpos + ((long)(f - 1) * pos_rows + p) * D + e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dp[i] += acc[i];
+            if (p == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) atomicAdd(dspace + e + i, acc[i]);
+            }
+        }
+    }
+}
+
+extern "C" int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos,
+                                void* x, int B, int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
+    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P) return ISTVT_ERR_SHAPE;
+    dim3 grid((unsigned)((long)B * F * P)), block(128);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tokens_fwd_kernel<T>), grid, block, 0, stream, (const T*)feats, space,
+                                             temporal, pos, (T*)x, B, F, P, D, pos_rows));
+    return istvt_check_launch();
+}
+
+// dfeats may be null (features do not require grad).  dspace/dtemporal/dpos accumulate (fp32).
+extern "C" int istvt_tokens_bwd(const void* dx, void* dfeats, float* dspace, float* dtemporal, float* dpos, int B,
+                                int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
+    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P) return ISTVT_ERR_SHAPE;
+    dim3 grid(P, F), block(128);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tokens_bwd_kernel<T>), grid, block, 0, stream, (const T*)dx, (T*)dfeats,
+                                             dspace, dtemporal, dpos, B, F, P, D, pos_rows));
+    return istvt_check_launch();
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Frame difference of TemporalResidualAttention (module.py:193) for callers that hand the module
+// an already-normalised input (the PreNorm path fuses this into layernorm.hip):
+//   forward : out[f] = x[f] - (f >= 2 ? x[f-1] : 0)
+//   backward: out[f] = g[f] - (1 <= f <= F-2 ? g[f+1] : 0)          (adjoint)
+template <typename T>
+__global__ __launch_bounds__(256) void frame_diff_kernel(const T* __restrict__ x, T* __restrict__ out, long M, int F,
+                                                         int P, int D, int adjoint) {
+    const long nvec = M * (D / 8);
+    const long stride = (long)gridDim.x * 256;
+    const int vpr = D / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const long m = i / vpr;
+        const int e = (int)(i % vpr) * 8;
+        const int f = (int)((m / P) % F);
+        float a[8];
+        load8(x + m * D + e, a);
+        const bool sub = adjoint ? (f >= 1 && f <= F - 2) : (f >= 2);
+        if (sub) {
+            float b[8];
+            load8(x + (adjoint ? m + P : m - P) * D + e, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] -= b[j];
+        }
+        store8(out + m * D + e, a);
+    }
+}
+
+extern "C" int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int adjoint, int dtype,
+                                hipStream_t stream) {
+    if (B <= 0 || F <= 0 || P <= 0 || D % 8 != 0) return ISTVT_ERR_SHAPE;
+    const long M = (long)B * F * P;
+    long blocks = (M * (D / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks), block(256);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((frame_diff_kernel<T>), grid, block, 0, stream, (const T*)x, (T*)out, M, F,
+                                             P, D, adjoint));
+    return istvt_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// dtype casts (fp32 master weights -> bf16 GEMM operands; T -> fp32 for the loss head)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * 256 * 8;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            float v[8];
+            load8(in + i, v);
+            store8(out + i, v);
+        } else {
+            for (long j = i; j < n; ++j) out[j] = from_f32<TO>(to_f32(in[j]));
+        }
+    }
+}
+
+extern "C" int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, hipStream_t stream) {
+    if (n <= 0) return ISTVT_ERR_SHAPE;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks), block(256);
+    if (in_dtype == DT_F32 && out_dtype == DT_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)in, (bf16_t*)out, n);
+    else if (in_dtype == DT_BF16 && out_dtype == DT_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)in, (float*)out, n);
+    else if (in_dtype == DT_F32 && out_dtype == DT_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, stream, (const float*)in, (float*)out, n);
+    else if (in_dtype == DT_BF16 && out_dtype == DT_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, n);
+    else return ISTVT_ERR_DTYPE;
+    return istvt_check_launch();
+}

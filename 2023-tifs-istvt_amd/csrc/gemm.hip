@@ -1,0 +1,280 @@
+// MFMA GEMM with fused epilogues for gfx950.
+//
+//   C[m][n] = epi( sum_k A(m,k) * B(n,k) )          m < M, n < N, k < K
+//
+// Replaces every nn.Linear of the transformer (reference network/vivit/module.py:27,30,74,77,
+// 182,183,186; network/vivit/vivit.py:129) and every 1x1 / im2col'd convolution of the stem
+// (network/xception.py:44,57,118,122), forward, input-gradient and weight-gradient:
+//   forward  y = x W^T      : A = x  [M][K] k-contiguous,  B = W  [N][K] k-contiguous
+//   dgrad    dx = dy W      : A = dy [M][K] k-contiguous,  B = W  [K][N] n-contiguous (a_kc=1,b_kc=0)
+//   wgrad    dW = dy^T x    : A = dy [K][M] m-contiguous,  B = x  [K][N] n-contiguous (a_kc=0,b_kc=0)
+//
+// Tile: 128x128 per 256-thread workgroup (4 wavefronts as 2x2, 64x64 each = 4x4 MFMA 16x16 tiles),
+// BK = 64 (bf16) / 32 (f32), register-prefetched global->LDS staging, padded LDS rows.
+// MFMA operands are swapped (weights as A-operand) so a lane owns 4 consecutive output columns
+// -> 8/16-byte epilogue accesses.  bf16: v_mfma_f32_16x16x32_bf16, transposed operands read with
+// ds_read_b64_tr_b16; f32: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+#include "common.h"
+
+#define EPI_NONE 0
+#define EPI_GELU_FWD 1   // C = u (pre-activation), C2 = gelu(u)
+#define EPI_GELU_BWD 2   // C = acc * gelu'(U), U given in C2
+
+struct GemmArgs {
+    const void* A; const void* B; void* C; void* C2;
+    const float* bias; const void* residual;
+    long lda, ldb, ldc, ldr;
+    int M, N, K;
+    int epi;
+    int atomic_f32;       // accumulate into float C with atomics (split-K weight gradients)
+    int out_f32;          // C is float regardless of T (plain store)
+    int kper;             // K range per blockIdx.z
+    int a_vec, b_vec;     // 16-byte vector loads legal for the operand
+    float alpha;
+};
+
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+template <typename T> struct Tile { static constexpr int BK = 32; };
+template <> struct Tile<bf16_t> { static constexpr int BK = 64; };
+
+constexpr int BM = 128, BN = 128;
+constexpr int KPAD = 8;      // row padding (elements) of a k-contiguous LDS image
+constexpr int RPAD = 8;      // row padding of a rows-contiguous LDS image
+
+// one staged operand tile held in registers between the global load and the LDS store
+template <typename T, int BK> struct Stage {
+    static constexpr int NV = (128 * BK / 8) / 256;     // 8-element vectors per thread
+    typename Mma<T>::frag v[NV];
+};
+
+__device__ __forceinline__ void frag_store(bf16_t* p, const bf16x8& f) { *reinterpret_cast<bf16x8*>(p) = f; }
+__device__ __forceinline__ void frag_store(float* p, const f32frag& f) {
+    *reinterpret_cast<float4*>(p) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+
+// load a 128(rows) x BK(k) tile.  KC: src[row][k]; else src[k][row].
+template <typename T, int BK, bool KC>
+__device__ __forceinline__ void stage_load(Stage<T, BK>& st, const T* __restrict__ src, long ld, int row0, int nrows,
+                                           int k0, int kend, bool vec_ok, int tid) {
+    constexpr int NV = Stage<T, BK>::NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 256 * i;
+        int row, k;
+        if (KC) { row = v / (BK / 8); k = (v % (BK / 8)) * 8; }
+        else    { k = v / 16; row = (v % 16) * 8; }
+        const int grow = row0 + row, gk = k0 + k;
+        if (KC) {
+            if (grow < nrows && gk + 8 <= kend && vec_ok) {
+                st.v[i] = frag_load(src + (long)grow * ld + gk);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    Mma<T>::set(st.v[i], e, (grow < nrows && gk + e < kend) ? to_f32(src[(long)grow * ld + gk + e]) : 0.f);
+            }
+        } else {
+            if (gk < kend && grow + 8 <= nrows && vec_ok) {
+                st.v[i] = frag_load(src + (long)gk * ld + grow);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    Mma<T>::set(st.v[i], e, (gk < kend && grow + e < nrows) ? to_f32(src[(long)gk * ld + grow + e]) : 0.f);
+            }
+        }
+    }
+}
+
+template <typename T, int BK, bool KC>
+__device__ __forceinline__ void stage_store(const Stage<T, BK>& st, T* img, int tid) {
+    constexpr int NV = Stage<T, BK>::NV;
+    constexpr int LDK = BK + KPAD, LDR = 128 + RPAD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 256 * i;
+        if (KC) {
+            const int row = v / (BK / 8), k = (v % (BK / 8)) * 8;
+            frag_store(img + row * LDK + k, st.v[i]);
+        } else {
+            const int k = v / 16, row = (v % 16) * 8;
+            frag_store(img + k * LDR + row, st.v[i]);
+        }
+    }
+}
+
+template <typename T, int BK, bool KC>
+__device__ __forceinline__ typename Mma<T>::frag frag_get(const T* img, int row16, int ks, int g, int r) {
+    constexpr int LDK = BK + KPAD, LDR = 128 + RPAD;
+    if (KC) return frag_load(img + (row16 + r) * LDK + ks * 32 + 8 * g);
+    return frag_load_tr(img, LDR, ks * 32 + 8 * g, ks * 32 + 8 * g + 4, row16, r);
+}
+
+template <typename T, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int BK = Tile<T>::BK;
+    constexpr int KS = BK / 32;
+    constexpr int A_ELEMS = A_KC ? 128 * (BK + KPAD) : BK * (128 + RPAD);
+    constexpr int B_ELEMS = B_KC ? 128 * (BK + KPAD) : BK * (128 + RPAD);
+    __shared__ __attribute__((aligned(16))) T smem[A_ELEMS + B_ELEMS];
+    T* As = smem;
+    T* Bs = smem + A_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: blocks that share an XCD (id % 8) get consecutive tiles, tiles run
+    // n-fastest so one XCD's L2 keeps an A row-panel while sweeping the (few) column tiles.
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_n * tiles_m;
+    int id = blockIdx.x;
+    {
+        const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+    }
+    const int bm0 = (id / tiles_n) * BM, bn0 = (id % tiles_n) * BN;
+    const int k_begin = blockIdx.z * p.kper;
+    const int k_end = min(p.K, k_begin + p.kper);
+
+    const T* A = (const T*)p.A;
+    const T* B = (const T*)p.B;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage<T, BK> sa, sb;
+    const bool avec = p.a_vec != 0, bvec = p.b_vec != 0;
+    stage_load<T, BK, A_KC>(sa, A, p.lda, bm0, p.M, k_begin, k_end, avec, tid);
+    stage_load<T, BK, B_KC>(sb, B, p.ldb, bn0, p.N, k_begin, k_end, bvec, tid);
+    stage_store<T, BK, A_KC>(sa, As, tid);
+    stage_store<T, BK, B_KC>(sb, Bs, tid);
+    __syncthreads();
+
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) {
+            stage_load<T, BK, A_KC>(sa, A, p.lda, bm0, p.M, k0 + BK, k_end, avec, tid);
+            stage_load<T, BK, B_KC>(sb, B, p.ldb, bn0, p.N, k0 + BK, k_end, bvec, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            typename Mma<T>::frag af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = frag_get<T, BK, A_KC>(As, wm * 64 + t * 16, ks, g, r);
+                bf[t] = frag_get<T, BK, B_KC>(Bs, wn * 64 + t * 16, ks, g, r);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) Mma<T>::mma(acc[mt][nt], bf[nt], af[mt]);
+        }
+        __syncthreads();
+        if (more) {
+            stage_store<T, BK, A_KC>(sa, As, tid);
+            stage_store<T, BK, B_KC>(sb, Bs, tid);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = tile row r, n = 4g..4g+3 of each 16x16 tile
+    const bool nvec = (p.N % 4 == 0) && (p.ldc % 4 == 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = bm0 + wm * 64 + mt * 16 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = bn0 + wn * 64 + nt * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4] = {acc[mt][nt][0] * p.alpha, acc[mt][nt][1] * p.alpha, acc[mt][nt][2] * p.alpha,
+                          acc[mt][nt][3] * p.alpha};
+            const int nv = min(4, p.N - n);
+            if (p.bias && blockIdx.z == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j];
+            }
+            if (p.atomic_f32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < nv) atomicAdd(c + j, v[j]);
+                continue;
+            }
+            const long off = (long)m * p.ldc + n;
+            if (p.epi == EPI_GELU_FWD) {
+                float gv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] = gelu_f(v[j]);
+                T* c = (T*)p.C + off;
+                T* c2 = (T*)p.C2 + off;
+                if (nvec) { store4(c, v); store4(c2, gv); }
+                else { for (int j = 0; j < nv; ++j) { c[j] = from_f32<T>(v[j]); c2[j] = from_f32<T>(gv[j]); } }
+                continue;
+            }
+            if (p.epi == EPI_GELU_BWD) {
+                const T* u = (const T*)p.C2 + off;
+                float uv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (nvec) load4(u, uv); else { for (int j = 0; j < nv; ++j) uv[j] = to_f32(u[j]); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(uv[j]);
+            }
+            if (p.residual) {
+                const T* rp = (const T*)p.residual + (long)m * p.ldr + n;
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (nvec && (p.ldr % 4 == 0)) load4(rp, rv); else { for (int j = 0; j < nv; ++j) rv[j] = to_f32(rp[j]); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rv[j];
+            }
+            if (p.out_f32) {
+                float* c = (float*)p.C + off;
+                if (nvec) store4(c, v); else { for (int j = 0; j < nv; ++j) c[j] = v[j]; }
+            } else {
+                T* c = (T*)p.C + off;
+                if (nvec) store4(c, v); else { for (int j = 0; j < nv; ++j) c[j] = from_f32<T>(v[j]); }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_gemm(const GemmArgs& a, int a_kc, int b_kc, int splitk, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, splitk), block(256);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, 0, stream, a);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, stream, a);
+    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, stream, a);
+    else return ISTVT_ERR_SHAPE;
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc,
+                          int M, int N, int K, const float* bias, const void* residual, long ldr, void* C2, int epi,
+                          int out_mode, int splitk, float alpha, int dtype, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return ISTVT_ERR_SHAPE;
+    if (out_mode < 0 || out_mode > 2 || epi < 0 || epi > 2) return ISTVT_ERR_SHAPE;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1 && out_mode != 2) return ISTVT_ERR_SHAPE;       // split-K only with atomic accumulation
+    const int esz = dtype == DT_F32 ? 4 : 2;
+    const int bk = dtype == DT_F32 ? 32 : 64;
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.residual = residual;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epi = epi;
+    a.out_f32 = out_mode == 1; a.atomic_f32 = out_mode == 2; a.alpha = alpha;
+    int kper = (K + splitk - 1) / splitk;
+    kper = ((kper + bk - 1) / bk) * bk;
+    a.kper = kper;
+    splitk = (K + kper - 1) / kper;
+    a.a_vec = (((uintptr_t)A % 16) == 0 && (lda * esz) % 16 == 0) ? 1 : 0;
+    a.b_vec = (((uintptr_t)B % 16) == 0 && (ldb * esz) % 16 == 0) ? 1 : 0;
+    DISPATCH_DTYPE(dtype, return launch_gemm<T>(a, a_kc, b_kc, splitk, stream));
+    return ISTVT_OK;
+}

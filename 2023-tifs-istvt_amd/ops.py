@@ -1,0 +1,292 @@
+"""Tensor-level launch wrappers around the C ABI (include/istvt_hip.h).
+
+Every function checks shapes/dtypes in Python *before* launching (so bad geometry raises a
+Python exception like the reference does, SURVEY.md 8(b) "Error convention"), passes raw device
+pointers + the current torch stream, and never synchronises.  Inputs must live on a ROCm
+device: there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def dtype_code(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError('istvt_amd supports float32 and bfloat16 activations, got %s' % t.dtype) from None
+
+
+def _req(t: Tensor, name: str = 'tensor') -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError('istvt_amd: %s must be on a ROCm device (no CPU fallback exists for the ISTVT hot path)' % name)
+    return t
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------
+# fp32 master weight -> compute-dtype operand, cached per parameter version
+_wcache: 'weakref.WeakKeyDictionary[Tensor, Tuple[int, Tensor]]' = weakref.WeakKeyDictionary()
+
+
+def cast(t: Tensor, dtype: torch.dtype) -> Tensor:
+    _req(t)
+    if t.dtype == dtype:
+        return t
+    t = _c(t)
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    if t.numel():
+        _lib.check(_lib.lib().istvt_cast(t.data_ptr(), dtype_code(t), out.data_ptr(), _DT[dtype], t.numel(), _stream()),
+                   'istvt_cast')
+    return out
+
+
+def weight_as(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """Contiguous 2-D view of a (fp32) parameter in the compute dtype; bf16 copies are cached
+    until the parameter is modified in place (optimizer step bumps ``_version``)."""
+    w2 = w.detach()
+    if w2.dim() != 2:
+        w2 = w2.reshape(w2.shape[0], -1)
+    if w2.dtype == dtype:
+        return _c(w2)
+    hit = _wcache.get(w)
+    if hit is not None and hit[0] == w._version and hit[1].dtype == dtype:
+        return hit[1]
+    out = cast(w2, dtype)
+    _wcache[w] = (w._version, out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
+             K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
+             C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0):
+    _req(A); _req(B); _req(C)
+    if A.dtype != B.dtype:
+        raise TypeError('gemm operands must share a dtype (%s vs %s)' % (A.dtype, B.dtype))
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError('bias must be float32')
+    rc = _lib.lib().istvt_gemm(A.data_ptr(), lda, int(a_kc), B.data_ptr(), ldb, int(b_kc), C.data_ptr(), ldc, M, N, K,
+                               _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
+                               dtype_code(A), _stream())
+    _lib.check(rc, 'istvt_gemm')
+
+
+def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+               gelu: bool = False):
+    """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError('linear: weight %s does not match input width %d' % (tuple(w.shape), K))
+    x = _c(x)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if gelu:
+        g = torch.empty_like(y)
+        gemm_raw(x, K, True, w, K, True, y, N, M, N, K, bias=bias, C2=g, epi=1)
+        return y, g
+    if residual is not None:
+        residual = _c(residual)
+    gemm_raw(x, K, True, w, K, True, y, N, M, N, K, bias=bias, residual=residual, ldr=N)
+    return y
+
+
+def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None) -> Tensor:
+    """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    dy = _c(dy)
+    dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    if gelu_u is not None:
+        gemm_raw(dy, N, True, w, K, False, dx, K, M, K, N, C2=_c(gelu_u), epi=2)
+    else:
+        gemm_raw(dy, N, True, w, K, False, dx, K, M, K, N)
+    return dx
+
+
+def _pick_splitk(out_rows: int, out_cols: int, red: int) -> int:
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    s = max(1, 1024 // tiles)
+    s = min(s, max(1, red // 512))
+    return s
+
+
+def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """out[N,K] (+)= dy.T @ x   (dy [M,N], x [M,K]); fp32 accumulate via split-K atomics."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dy, x = _c(dy), _c(x)
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    gemm_raw(dy, N, False, x, K, False, out, K, N, K, M, out_mode=2, splitk=_pick_splitk(N, K, M))
+    return out
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    M, N = x.shape
+    x = _c(_req(x))
+    if out is None:
+        out = torch.zeros((N,), dtype=torch.float32, device=x.device)
+    if N % 8 == 0:
+        _lib.check(_lib.lib().istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, N, dtype_code(x), _stream()), 'istvt_colsum')
+    else:
+        # narrow outputs (e.g. the 1-logit head): a [N][1] GEMM against ones keeps it on the HIP path
+        ones = torch.ones((M, 8), dtype=x.dtype, device=x.device)
+        tmp = torch.zeros((N, 8), dtype=torch.float32, device=x.device)
+        gemm_raw(x, N, False, ones, 8, False, tmp, 8, N, 8, M, out_mode=2, splitk=1)
+        out += tmp[:, 0]
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
+    x = _c(_req(x))
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(_lib.lib().istvt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), M, D, eps, dtype_code(x), _stream()),
+               'istvt_layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: int, F: int, P: int):
+    x = _c(_req(x))
+    D = x.shape[-1]
+    if x.numel() != B * F * P * D:
+        raise RuntimeError('layernorm_fwd_diff: %s is not (B=%d, F*P=%d*%d, D)' % (tuple(x.shape), B, F, P))
+    y = torch.empty_like(x)
+    diff = torch.empty_like(x)
+    M = B * F * P
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                   diff.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, F, P, D, eps,
+                                                   dtype_code(x), _stream()), 'istvt_layernorm_fwd_diff')
+    return y, diff, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
+                  dy2: Optional[Tensor] = None, dres: Optional[Tensor] = None, F: int = 1, P: int = 1) -> Tensor:
+    dy = _c(_req(dy))
+    D = x.shape[-1]
+    M = x.numel() // D
+    dx = torch.empty_like(x)
+    if dy2 is not None:
+        dy2 = _c(dy2)
+    if dres is not None:
+        dres = _c(dres)
+    _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), _ptr(dy2), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              gamma.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
+                                              dbeta.data_ptr(), M, D, F, P, dtype_code(x), _stream()),
+               'istvt_layernorm_bwd')
+    return dx
+
+
+# ------------------------------------------------------------------------------------------
+def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int):
+    qkv = _c(_req(qkv))
+    inner = heads * dh
+    if qkv.numel() != BF * P * 3 * inner:
+        raise RuntimeError('attn_spatial: qkv %s is not (%d*%d, 3*%d)' % (tuple(qkv.shape), BF, P, inner))
+    out = torch.empty((BF * P, inner), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().istvt_attn_spatial_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh,
+                                                 dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_fwd')
+    return out, lse
+
+
+def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: int, P: int, heads: int, dh: int) -> Tensor:
+    dout = _c(_req(dout))
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    _lib.check(_lib.lib().istvt_attn_spatial_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                                 delta.data_ptr(), dqkv.data_ptr(), BF, P, heads, dh, dh ** -0.5,
+                                                 dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
+    return dqkv
+
+
+def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int, dh: int):
+    qk, v = _c(_req(qk)), _c(_req(v))
+    inner = heads * dh
+    if F > 17:
+        raise RuntimeError('attn_temporal: at most 17 frames (T <= 16) are supported, got F=%d' % F)
+    if qk.numel() != B * F * P * 2 * inner or v.numel() != B * F * P * inner:
+        raise RuntimeError('attn_temporal: shapes %s / %s do not match B=%d F=%d P=%d' % (tuple(qk.shape), tuple(v.shape), B, F, P))
+    out = torch.empty((B * F * P, inner), dtype=qk.dtype, device=qk.device)
+    lse = torch.empty((B * F * P, heads), dtype=torch.float32, device=qk.device)
+    _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, F, P,
+                                                  heads, dh, dh ** -0.5, dtype_code(qk), _stream()),
+               'istvt_attn_temporal_fwd')
+    return out, lse
+
+
+def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, lse: Tensor, B: int, F: int, P: int, heads: int, dh: int):
+    dout = _c(_req(dout))
+    dqk = torch.empty_like(qk)
+    dv = torch.empty_like(v)
+    _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), v.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                                  dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
+                                                  dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
+    return dqk, dv
+
+
+# ------------------------------------------------------------------------------------------
+def tokens_fwd(feats: Tensor, space: Tensor, temporal: Tensor, pos: Tensor) -> Tensor:
+    """feats [B,T,hw,D] -> x [B,(T+1)*(hw+1),D]; pos is the full (1,T,P_decl,D) parameter."""
+    feats = _c(_req(feats))
+    B, T, hw, D = feats.shape
+    F, P = T + 1, hw + 1
+    if pos.shape[1] != T:
+        raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1'
+                           % (T, pos.shape[1]))          # same failure the reference hits at vivit.py:138
+    if pos.shape[2] < P:
+        raise RuntimeError('pos_embedding has %d tokens per frame, input needs %d' % (pos.shape[2], P))
+    x = torch.empty((B, F * P, D), dtype=feats.dtype, device=feats.device)
+    _lib.check(_lib.lib().istvt_tokens_fwd(feats.data_ptr(), space.data_ptr(), temporal.data_ptr(), pos.data_ptr(),
+                                           x.data_ptr(), B, F, P, D, pos.shape[2], dtype_code(feats), _stream()),
+               'istvt_tokens_fwd')
+    return x
+
+
+def tokens_bwd(dx: Tensor, B: int, T: int, hw: int, D: int, dspace: Tensor, dtemporal: Tensor, dpos: Tensor,
+               need_dfeats: bool) -> Optional[Tensor]:
+    dx = _c(_req(dx))
+    F, P = T + 1, hw + 1
+    dfeats = torch.empty((B, T, hw, D), dtype=dx.dtype, device=dx.device) if need_dfeats else None
+    _lib.check(_lib.lib().istvt_tokens_bwd(dx.data_ptr(), _ptr(dfeats), dspace.data_ptr(), dtemporal.data_ptr(),
+                                           dpos.data_ptr(), B, F, P, D, dpos.shape[2], dtype_code(dx), _stream()),
+               'istvt_tokens_bwd')
+    return dfeats
+
+
+def frame_diff(x: Tensor, B: int, F: int, P: int, adjoint: bool = False) -> Tensor:
+    x = _c(_req(x))
+    D = x.shape[-1]
+    if x.numel() != B * F * P * D:
+        raise RuntimeError('frame_diff: %s is not (B=%d, F=%d, P=%d, D)' % (tuple(x.shape), B, F, P))
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().istvt_frame_diff(x.data_ptr(), out.data_ptr(), B, F, P, D, int(adjoint), dtype_code(x),
+                                           _stream()), 'istvt_frame_diff')
+    return out

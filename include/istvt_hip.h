@@ -1,0 +1,94 @@
+/*
+ * istvt_hip.h — C ABI of libistvt_hip.so, the MI355X (gfx950) kernels behind the ISTVT
+ * video-clip forward/backward hot path.
+ *
+ * The reference (Vill-Lab/2023-TIFS-ISTVT) is pure PyTorch: it has no FFI for this path; its
+ * "interface" is the chain of torch ops inside network/xception.py, network/vivit/module.py
+ * and network/vivit/vivit.py.  Each entry point below names the reference ops it replaces
+ * (file:line into /root/reference).  INTEGRATION.md shows the ctypes stubs that bind them.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates everything);
+ *     kernels never allocate, free, or retain pointers, and only enqueue on `stream`
+ *     (hipStream_t passed as void*; no host synchronisation).
+ *   - `dtype`: storage type of activations: 0 = float32 (parity mode), 1 = bfloat16.
+ *     Parameters, statistics, parameter gradients and all accumulation are float32.
+ *   - return value: 0 = ok; -2 = bad dtype; -3 = bad shape/argument; -(1000+e) = hipError_t e
+ *     raised by the launch.  Nothing throws, nothing exits.
+ *   - "accumulate" outputs (parameter gradients) are added to, so the caller zeroes them
+ *     (they are the .grad buffers).
+ *   - row-major everywhere; activations of the transformer are [M = B*F*P][D] with rows
+ *     ordered (clip b, frame f, token p); stem activations are NHWC [frames][H][W][C].
+ */
+#ifndef ISTVT_HIP_H
+#define ISTVT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* istvt_stream_t; /* hipStream_t */
+
+#define ISTVT_F32 0
+#define ISTVT_BF16 1
+
+/* ---- GEMM with fused epilogue -------------------------------------------------------------
+ * C[m][n] = epi(alpha * sum_k A(m,k) B(n,k)) ; a_kc/b_kc = 1: operand stored [rows][K]
+ * (K contiguous), 0: stored [K][rows].
+ * Replaces nn.Linear (module.py:27,30,74,77,182,183,186; vivit.py:129), 1x1 convs
+ * (xception.py:44,57) and the im2col'd 3x3 convs (xception.py:118,122): forward (1,1),
+ * input gradient (1,0) and weight gradient (0,0).
+ * bias: float[N] or NULL.  residual: T[M][ldr] or NULL (added after activation handling).
+ * epi: 0 none; 1 GELU forward (exact erf, module.py:28): C = pre-activation, C2 = gelu;
+ *      2 GELU backward: C = acc * gelu'(C2).
+ * out_mode: 0 store T; 1 store float; 2 atomicAdd into float C (required when splitk > 1). */
+int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
+               int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
+               float alpha, int dtype, istvt_stream_t stream);
+
+/* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
+int istvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        long M, int D, float eps, int dtype, istvt_stream_t stream);
+/* also writes diff = frame difference of y (module.py:193): rows (b,f,p), diff[f] = y[f] - y[f-1] for f >= 2 */
+int istvt_layernorm_fwd_diff(const void* x, const float* gamma, const float* beta, void* y, void* diff, float* mean,
+                             float* rstd, int B, int F, int P, int D, float eps, int dtype, istvt_stream_t stream);
+/* dy2 (may be NULL) = gradient w.r.t. diff; dres (may be NULL) = gradient arriving through the
+ * residual connection, added to dx.  dgamma/dbeta accumulate. */
+int istvt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* mean, const float* rstd,
+                        const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, long M, int D,
+                        int F, int P, int dtype, istvt_stream_t stream);
+
+/* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
+ * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)'), out [BF*P][heads*dh], lse [BF*P][heads]. */
+int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh, float scale,
+                           int dtype, istvt_stream_t stream);
+int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta_scratch,
+                           void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
+                           istvt_stream_t stream);
+
+/* ---- temporal attention (TemporalResidualAttention.forward core, module.py:197-205) --------
+ * qk [B*F*P][2*heads*dh] (q|k), v/out [B*F*P][heads*dh], rows (b,f,p); F <= 17. */
+int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, float* lse, int B, int F, int P, int heads,
+                            int dh, float scale, int dtype, istvt_stream_t stream);
+int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, const float* lse, void* dqk, void* dv,
+                            int B, int F, int P, int heads, int dh, float scale, int dtype, istvt_stream_t stream);
+
+/* ---- token assembly (DSTTr.forward, vivit.py:133-142) -------------------------------------- */
+int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, int B,
+                     int F, int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
+int istvt_tokens_bwd(const void* dx, void* dfeats, float* dspace, float* dtemporal, float* dpos, int B, int F, int P,
+                     int D, int pos_rows, int dtype, istvt_stream_t stream);
+
+/* frame difference of module.py:193 (adjoint = 1: its transpose, for the backward) */
+int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int adjoint, int dtype,
+                     istvt_stream_t stream);
+
+/* ---- helpers -------------------------------------------------------------------------------- */
+/* out[n] += sum_m x[m][n]  (bias gradients) */
+int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, istvt_stream_t stream);
+int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, istvt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISTVT_HIP_H */

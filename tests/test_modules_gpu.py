@@ -1,0 +1,122 @@
+"""HIP nn.Modules vs the golden vectors captured from the reference (G2, G3, G4, G6) and vs
+the oracle at geometries the reference cannot run (14x14 / 6x6 grids).  float32 parity mode:
+logits rtol 1e-3 (north_star), gradients 1e-2 on norms; observed errors are ~1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import recipe  # noqa: E402
+
+
+def _mods():
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network.vivit import module as M, vivit as V
+    return M, V
+
+
+def relerr(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b), dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def load_recipe(mod, prefix):
+    sd = mod.state_dict()
+    mod.load_state_dict({k: torch.from_numpy(recipe.param_value(prefix + k, tuple(v.shape))) for k, v in sd.items()})
+    return mod.cuda()
+
+
+DIM, HEADS, DH = 64, 2, 32
+ROW_STRIDE = {5: 3, 9: 7}
+TOL32 = 1e-4
+
+
+def _run(mod, x_name, shape):
+    x = torch.from_numpy(recipe.input_value(x_name, shape)).cuda().requires_grad_(True)
+    y = mod(x)
+    coef = torch.from_numpy(recipe.input_value(x_name + '.coef', tuple(y.shape))).cuda()
+    (y * coef).sum().backward()
+    return x, y
+
+
+@pytest.mark.parametrize('frames', [5, 9])
+@pytest.mark.parametrize('name', ['prenorm_ff', 'ff', 'spatial', 'temporal'])
+def test_g2_modules_hip(golden_dir, name, frames):
+    M, V = _mods()
+    g = np.load(os.path.join(golden_dir, 'G2_modules.npz'))
+    mod = {'prenorm_ff': lambda: M.PreNorm(DIM, M.FeedForward(DIM, 4 * DIM)),
+           'ff': lambda: M.FeedForward(DIM, 4 * DIM),
+           'spatial': lambda: M.SpatialOnlyAttention(DIM, heads=HEADS, dim_head=DH),
+           'temporal': lambda: M.TemporalResidualAttention(DIM, heads=HEADS, dim_head=DH)}[name]()
+    load_recipe(mod, 'g2.%s.' % name)
+    x, y = _run(mod, 'g2.%s.F%d' % (name, frames), (1, frames * 362, DIM))
+    tag = 'F%d.%s.' % (frames, name)
+    st = ROW_STRIDE[frames]
+    assert relerr(y[:, ::st], g[tag + 'y']) < TOL32
+    assert relerr(x.grad[:, ::st], g[tag + 'dx']) < TOL32
+    for k, p in mod.named_parameters():
+        assert relerr(p.grad, g[tag + 'grad.' + k]) < TOL32, k
+
+
+def test_g3_sttransformer_hip(golden_dir):
+    M, V = _mods()
+    g = np.load(os.path.join(golden_dir, 'G3_sttransformer.npz'))
+    mod = load_recipe(V.STTransformer(DIM, 2, HEADS, DH, 2 * DIM), 'g3.')
+    x, y = _run(mod, 'g3.x', (1, 5 * 362, DIM))
+    assert relerr(y[:, ::3], g['y']) < TOL32
+    assert relerr(x.grad[:, ::3], g['dx']) < TOL32
+    for k, p in mod.named_parameters():
+        assert relerr(p.grad, g['grad.' + k]) < 2e-4, k
+
+
+@pytest.mark.parametrize('T', [4, 8])
+def test_g4_dsttr_hip(golden_dir, T):
+    M, V = _mods()
+    g = np.load(os.path.join(golden_dir, 'G4_dsttr.npz'))
+    mod = load_recipe(V.DSTTr(19, 1, 1, T, dim=DIM, depth=2, heads=HEADS, dim_head=DH, in_channels=DIM, scale_dim=2), 'g4.')
+    x = torch.from_numpy(recipe.input_value('g4.x.T%d' % T, (2, T, DIM, 19, 19))).cuda().requires_grad_(True)
+    y = mod(x)
+    coef = torch.from_numpy(recipe.input_value('g4.coef', tuple(y.shape))).cuda()
+    (y * coef).sum().backward()
+    tag = 'T%d.' % T
+    assert relerr(y, g[tag + 'logits']) < 1e-4          # north_star: logits rtol 1e-3
+    assert relerr(x.grad.flatten(2).norm(dim=2), g[tag + 'dx_frame_norms']) < 1e-3
+    for k, p in mod.named_parameters():
+        assert relerr(p.grad.norm(), g[tag + 'gnorm.' + k]) < 1e-3, k
+    assert relerr(mod.pos_embedding.grad[0, :, ::37], g[tag + 'grad.pos_embedding']) < 1e-3
+    assert relerr(mod.space_token.grad, g[tag + 'grad.space_token']) < 1e-3
+    assert relerr(mod.temporal_token.grad, g[tag + 'grad.temporal_token']) < 1e-3
+
+
+def test_g6_fullwidth_hip(golden_dir):
+    """dim 728 / 8 heads x 64 at the reference-native 19x19 grid (pins the K=728 tiling)."""
+    M, V = _mods()
+    g = np.load(os.path.join(golden_dir, 'G6_fullwidth.npz'))
+    mod = load_recipe(V.DSTTr(19, 1, 1, 8, depth=2), 'vit.')
+    x = torch.from_numpy(recipe.input_value('g6.x', (1, 8, 728, 19, 19))).cuda().requires_grad_(True)
+    y = mod(x)
+    y.sum().backward()
+    assert relerr(y, g['logits']) < 1e-4
+    assert relerr(x.grad.flatten(2).norm(dim=2), g['dx_frame_norms']) < 1e-3
+    for k, p in mod.named_parameters():
+        assert relerr(p.grad.norm(), g['gnorm.' + k]) < 1e-3, k
+    qk0 = dict(mod.named_parameters())['transformer.layers.0.0.fn.to_qk.weight'].grad
+    assert relerr(qk0.reshape(-1)[:256], g['grad.qk0']) < 1e-3
+
+
+def test_wrong_geometry_raises():
+    """reference failure modes survive: wrong T (vivit.py:138) and indivisible token count (module.py:84)."""
+    M, V = _mods()
+    mod = V.DSTTr(6, 1, 1, 4, dim=DIM, depth=1, heads=HEADS, dim_head=DH, in_channels=DIM).cuda()
+    with pytest.raises(RuntimeError):
+        mod(torch.zeros(1, 5, DIM, 6, 6, device='cuda'))
+    att = M.SpatialOnlyAttention(DIM, heads=HEADS, dim_head=DH).cuda()
+    with pytest.raises(RuntimeError):
+        att(torch.zeros(1, 5 * 37, DIM, device='cuda'))
+    with pytest.raises(RuntimeError):           # CPU tensors are refused: no fallback path
+        M.FeedForward(DIM, 2 * DIM)(torch.zeros(1, 4, DIM))
