@@ -20,8 +20,8 @@ SIGNATURES = {
     'istvt_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
     'istvt_attn_spatial_fwd': [P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_bwd': [P, P, P, P, P, P, I, I, I, I, F, I, P],
-    'istvt_attn_temporal_fwd': [P, P, P, P, I, I, I, I, I, F, I, P],
-    'istvt_attn_temporal_bwd': [P, P, P, P, P, P, I, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_fwd': [P, P, P, I, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_bwd': [P, P, P, P, P, I, I, I, I, I, F, I, P],
     'istvt_tokens_fwd': [P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_tokens_bwd': [P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],

@@ -185,7 +185,13 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const T* __restrict__ qk
             float v[4] = {o[dt][u][0] * inv, o[dt][u][1] * inv, o[dt][u][2] * inv, o[dt][u][3] * inv};
             store4(op + 16 * dt + 4 * g, v);
         }
-        if (g == 0) lse[((long)bf * P + q) * heads + h] = (m_run[u] + log2f(l_run[u])) * LN2;
+        if (g == 0) {
+            // softmax statistics for backward: running max (log2 domain) and 1/sum, kept separate so
+            // that recomputed probabilities still sum to 1 to fp32 rounding (a fused log-sum-exp
+            // loses eps*|lse|, which p*(dP - delta) amplifies for peaked rows)
+            float2* st = reinterpret_cast<float2*>(lse) + ((long)bf * P + q) * heads + h;
+            *st = make_float2(m_run[u], inv);
+        }
     }
 }
 
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
     const float c = scale * LOG2E;
 
     typename Mma<T>::frag qf[2][KS], dof[2][KS];
-    float lq[2], dl[2];
+    float lq[2], li[2], dl[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int q = q0 + 16 * u + r;
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
             }
         }
         dl[u] = group_sum(part);
-        lq[u] = q < P ? lse[((long)bf * P + q) * heads + h] * LOG2E : 0.f;
+        const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
+        lq[u] = st.x; li[u] = st.y;
         if (q < P && g == 0) delta[((long)bf * P + q) * heads + h] = dl[u];
     }
 
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int key = c0 + 32 * ss + 16 * tt + 4 * g + j;
-                        const float pv = key < P ? fast_exp2(s[tt][u][j] * c - lq[u]) : 0.f;
+                        const float pv = key < P ? fast_exp2(s[tt][u][j] * c - lq[u]) * li[u] : 0.f;
                         s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]) * scale;       // dS^T
                     }
             }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
                                                             int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
-    __shared__ __attribute__((aligned(16))) float stat[2][CHUNK];
+    __shared__ __attribute__((aligned(16))) float stat[3][CHUNK];
     T* Qimg = smem;
     T* Dimg = smem + CHUNK * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
@@ -344,7 +351,10 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
         stage_img<T, DH>(Dimg, dop, inner, c0, P, tid);
         if (tid < CHUNK) {
             const int q = c0 + tid;
-            stat[0][tid] = q < P ? lse[((long)bf * P + q) * heads + h] * LOG2E : INFINITY;
+            const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h]
+                                    : make_float2(0.f, 0.f);        // 1/l = 0 masks padded query rows
+            stat[0][tid] = st.x;
+            stat[2][tid] = st.y;
             stat[1][tid] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
         }
         __syncthreads();
@@ -370,12 +380,14 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
                 const int qb = 32 * ss + 16 * tt + 4 * g;
                 const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][qb]);
                 const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][qb]);
+                const float4 i4 = *reinterpret_cast<const float4*>(&stat[2][qb]);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+                const float iv[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float pv = fast_exp2(s[tt][kt][j] * c - lv[j]);
+                        const float pv = fast_exp2(s[tt][kt][j] * c - lv[j]) * iv[j];
                         s[tt][kt][j] = pv;                                         // P
                         dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]) * scale;     // dS
                     }
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
         else return ISTVT_ERR_SHAPE;                            \
     } while (0)
 
-// qkv: [BF*P][3*heads*dh]; out: [BF*P][heads*dh]; lse: [BF*P][heads] (natural log)
+// qkv: [BF*P][3*heads*dh]; out: [BF*P][heads*dh]; lse: [BF*P][heads][2] = (row max in the log2 domain, 1/rowsum)
 extern "C" int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh,
                                       float scale, int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;

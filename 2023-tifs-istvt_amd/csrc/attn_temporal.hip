@@ -10,8 +10,8 @@
 // (DH elements) is one fully-coalesced cluster access, a wavefront touches 64/CL whole
 // DH-segments per instruction, dot products finish with log2(CL) DPP adds, no LDS.
 //
-// qk : [B*F*P][2*inner]  (q | k), v : [B*F*P][inner], out : [B*F*P][inner], rows ordered (b,f,p);
-// lse: [B*F*P][heads] natural-log softmax normaliser (saved for backward).
+// qk : [B*F*P][2*inner]  (q | k), v : [B*F*P][inner], out : [B*F*P][inner], rows ordered (b,f,p).
+// Nothing is saved for backward: the F x F probabilities are recomputed from q,k.
 #include "common.h"
 
 template <int CL> __device__ __forceinline__ float cluster_sum(float v) {
@@ -29,8 +29,8 @@ __device__ __forceinline__ float dot4(const float (&a)[4], const float (&b)[4]) 
 
 template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
-                                                        T* __restrict__ out, float* __restrict__ lse, int B, int F,
-                                                        int P, int heads, float scale) {
+                                                        T* __restrict__ out, int B, int F, int P, int heads,
+                                                        float scale) {
     constexpr int CL = DH / 4, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
             if (valid) {
                 const long m = row0 + (long)i * P;
                 store4(out + m * inner + col, o);
-                if (cl == 0) lse[m * heads + h] = mx + __logf(sum);
             }
         }
     }
@@ -94,9 +93,9 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
 // backward: dqk [B*F*P][2*inner] (dq | dk), dv [B*F*P][inner]
 template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
-                                                        const T* __restrict__ dout, const float* __restrict__ lse,
-                                                        T* __restrict__ dqk, T* __restrict__ dv, int B, int F, int P,
-                                                        int heads, float scale) {
+                                                        const T* __restrict__ dout, T* __restrict__ dqk,
+                                                        T* __restrict__ dv, int B, int F, int P, int heads,
+                                                        float scale) {
     constexpr int CL = DH / 4, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -128,17 +127,29 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
     for (int i = 0; i < FMAX; ++i) {
         if (i < F) {
             const long m = row0 + (long)i * P;
-            const float li = lse[m * heads + h];
+            // probabilities are recomputed exactly as the forward computes them (max, exp, sum,
+            // divide): a saved log-sum-exp would leave sum(p) != 1 by eps*|lse| and that error is
+            // amplified in p*(dp - delta) when the softmax is peaked.
             float pr[FMAX], dp[FMAX];
-            float delta = 0.f;
+            float mx = -INFINITY;
 #pragma unroll
             for (int j = 0; j < FMAX; ++j) {
                 if (j < F) {
-                    const float s = cluster_sum<CL>(dot4(q[i], k[j])) * scale;
-                    pr[j] = __expf(s - li);
+                    pr[j] = cluster_sum<CL>(dot4(q[i], k[j])) * scale;
+                    mx = fmaxf(mx, pr[j]);
                     dp[j] = cluster_sum<CL>(dot4(dO[i], vv[j]));
-                    delta += pr[j] * dp[j];
                 }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) { pr[j] = __expf(pr[j] - mx); sum += pr[j]; }
+            }
+            const float inv = 1.0f / sum;
+            float delta = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) { pr[j] *= inv; delta += pr[j] * dp[j]; }
             }
             float dq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -181,19 +192,17 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
         else return ISTVT_ERR_SHAPE;                                                                     \
     } while (0)
 
-extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, float* lse, int B, int F, int P,
-                                       int heads, int dh, float scale, int dtype, hipStream_t stream) {
+extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, int B, int F, int P, int heads,
+                                       int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, (const T*)qk, (const T*)v, (T*)out, lse, B, F, P, heads,
-                                         scale));
+    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P, heads, scale));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, const float* lse, void* dqk,
-                                       void* dv, int B, int F, int P, int heads, int dh, float scale, int dtype,
-                                       hipStream_t stream) {
+extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int B,
+                                       int F, int P, int heads, int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, (const T*)qk, (const T*)v, (const T*)dout, lse, (T*)dqk,
-                                         (T*)dv, B, F, P, heads, scale));
+    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, (const T*)qk, (const T*)v, (const T*)dout, (T*)dqk, (T*)dv,
+                                         B, F, P, heads, scale));
     return istvt_check_launch();
 }

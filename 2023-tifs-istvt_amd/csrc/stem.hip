@@ -1,0 +1,767 @@
+// Xception entry-flow kernels (reference: network/xception.py:39-101,118-128,193-206), NHWC
+// activations [frames][H][W][C] in the storage dtype T, fp32 statistics and parameters.
+//
+//   im2col (conv1: NCHW fp32 clip -> [M][32]; conv2: NHWC -> [M][9*C]) feeding the MFMA GEMM
+//   col2im (conv2 input gradient)
+//   train-mode BatchNorm: per-channel statistics (column reductions, fp64 atomics), finalize
+//       (mean/rstd/scale/shift + running-stat update), apply, backward statistics / apply
+//   depthwise 3x3 (pad 1) with an LDS input tile (halo loaded once per workgroup, the
+//       preceding BN-apply+ReLU fused into the tile load): forward, input gradient (flipped
+//       taps, ReLU mask / strided skip-gradient add / BN-backward statistics in the epilogue),
+//       weight gradient
+//   MaxPool(3,2,1) fused with both BN-applies and the skip add; its backward
+//   stride-2 pixel subsample for the 1x1 stride-2 skip convolutions
+//
+// All of these are HBM-bound (AI <= 4.5 flop/B): coalesced 16-byte accesses along C.
+#include "common.h"
+
+// ============================================================================================
+// column reductions over a [M][C] matrix, C % 8 == 0
+// ============================================================================================
+template <int NACC, typename F>
+__device__ __forceinline__ void colreduce_block(F f, double* const (&out)[NACC], long M, int C, int rows_per_block) {
+    __shared__ float red[NACC][256][8];
+    const int VC = C / 8;
+    const int vc0 = blockIdx.x * 256;
+    const int vcg = min(256, VC - vc0);
+    const int RS = 256 / vcg;
+    const int tcol = threadIdx.x % vcg, trow = threadIdx.x / vcg;
+    float acc[NACC][8];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[a][i] = 0.f;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + (long)rows_per_block);
+    const int c0 = (vc0 + tcol) * 8;
+    if (trow < RS)
+        for (long m = r0 + trow; m < r1; m += RS) f(m, c0, acc);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[a][threadIdx.x][i] = acc[a][i];
+    __syncthreads();
+    if (threadIdx.x < vcg) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float s = 0.f;
+                for (int t = 0; t < RS; ++t) s += red[a][threadIdx.x + t * vcg][i];
+                atomicAdd(out[a] + c0 + i, (double)s);
+            }
+    }
+}
+
+static void colreduce_grid(long M, int C, dim3& grid, int& rpb) {
+    const int gx = (C / 8 + 255) / 256;
+    long target = 2048 / gx;
+    if (target < 1) target = 1;
+    rpb = (int)((M + target - 1) / target);
+    if (rpb < 32) rpb = 32;
+    grid = dim3(gx, (unsigned)((M + rpb - 1) / rpb));
+}
+
+// sum[c] += sum_m x ; sumsq[c] += sum_m x^2       (nn.BatchNorm2d batch statistics)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, double* sum, double* sumsq, long M,
+                                                       int C, int rpb) {
+    double* const outs[2] = {sum, sumsq};
+    colreduce_block<2>([&](long m, int c0, float (&acc)[2][8]) {
+        float v[8];
+        load8(x + m * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[0][i] += v[i]; acc[1][i] += v[i] * v[i]; }
+    }, outs, M, C, rpb);
+}
+
+// s1[c] += sum_m dz ; s2[c] += sum_m dz * xhat,  xhat = (u - mean) * rstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ dz, const T* __restrict__ u,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, double* s1, double* s2,
+                                                           long M, int C, int rpb) {
+    double* const outs[2] = {s1, s2};
+    colreduce_block<2>([&](long m, int c0, float (&acc)[2][8]) {
+        float d[8], uv[8], mu[8], rs[8];
+        load8(dz + m * C + c0, d);
+        load8(u + m * C + c0, uv);
+        load8(mean + c0, mu);
+        load8(rstd + c0, rs);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[0][i] += d[i]; acc[1][i] += d[i] * (uv[i] - mu[i]) * rs[i]; }
+    }, outs, M, C, rpb);
+}
+
+// finalize: batch (use_batch=1) or running statistics -> mean, rstd, scale = g*rstd, shift = b - mean*scale;
+// updates running stats like torch (momentum, unbiased variance) when update_running.
+__global__ void bn_finalize_kernel(const double* sum, const double* sumsq, double count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                   float* mean_o, float* rstd_o, float* scale_o, float* shift_o, int C, int use_batch,
+                                   int update_running) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (use_batch) {
+        mean = sum[c] / count;
+        var = sumsq[c] / count - mean * mean;
+        if (var < 0) var = 0;
+        if (update_running) {
+            const double unb = count > 1 ? var * count / (count - 1) : var;
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+        }
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - (float)mean * sc;
+}
+
+// y = x * scale + shift (optionally ReLU)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, T* __restrict__ y, long M,
+                                                       int C, int relu) {
+    const int vpr = C / 8;
+    const long nvec = M * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const int c0 = (int)(i % vpr) * 8;
+        float v[8], sc[8], sh[8];
+        load8(x + i * 8, v);
+        load8(scale + c0, sc);
+        load8(shift + c0, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = v[j] * sc[j] + sh[j];
+            if (relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        store8(y + i * 8, v);
+    }
+}
+
+// du = gamma*rstd * (dz - s1/M - xhat * s2/M);  dgamma += s2 ; dbeta += s1 (block 0 only)
+// relu_mask: dz is first masked by (scale*u + shift > 0) -- only legal when s1/s2 were computed
+// from the masked dz, so the mask is applied by the producer instead; kept out of this kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ u,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* s1,
+                                                           const double* s2, T* __restrict__ du, float* dgamma,
+                                                           float* dbeta, long M, int C) {
+    const int vpr = C / 8;
+    const long nvec = M * vpr, stride = (long)gridDim.x * 256;
+    const float invM = 1.0f / (float)M;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const int c0 = (int)(i % vpr) * 8;
+        float d[8], uv[8], mu[8], rs[8], g[8];
+        load8(dz + i * 8, d);
+        load8(u + i * 8, uv);
+        load8(mean + c0, mu);
+        load8(rstd + c0, rs);
+        load8(gamma + c0, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (uv[j] - mu[j]) * rs[j];
+            d[j] = g[j] * rs[j] * (d[j] - (float)s1[c0 + j] * invM - xh * (float)s2[c0 + j] * invM);
+        }
+        store8(du + i * 8, d);
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            if (dgamma) dgamma[c] += (float)s2[c];
+            if (dbeta) dbeta[c] += (float)s1[c];
+        }
+    }
+}
+
+static int ew_grid(long nvec) {
+    long b = (nvec + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int istvt_bn_stats(const void* x, double* sum, double* sumsq, long M, int C, int dtype, hipStream_t stream) {
+    if (M <= 0 || C <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    dim3 grid; int rpb;
+    colreduce_grid(M, C, grid, rpb);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), grid, dim3(256), 0, stream, (const T*)x, sum, sumsq, M, C, rpb));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma,
+                                 const float* beta, float* rmean, float* rvar, float momentum, float eps, float* mean,
+                                 float* rstd, float* scale, float* shift, int C, int use_batch, int update_running,
+                                 hipStream_t stream) {
+    if (C <= 0) return ISTVT_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, count, gamma, beta,
+                       rmean, rvar, momentum, eps, mean, rstd, scale, shift, C, use_batch, update_running);
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_bn_apply(const void* x, const float* scale, const float* shift, void* y, long M, int C, int relu,
+                              int dtype, hipStream_t stream) {
+    if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0, stream,
+                                             (const T*)x, scale, shift, (T*)y, M, C, relu));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_bn_bwd_stats(const void* dz, const void* u, const float* mean, const float* rstd, double* s1,
+                                  double* s2, long M, int C, int dtype, hipStream_t stream) {
+    if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    dim3 grid; int rpb;
+    colreduce_grid(M, C, grid, rpb);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
+                                             (const T*)u, mean, rstd, s1, s2, M, C, rpb));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_bn_bwd_apply(const void* dz, const void* u, const float* mean, const float* rstd,
+                                  const float* gamma, const double* s1, const double* s2, void* du, float* dgamma,
+                                  float* dbeta, long M, int C, int dtype, hipStream_t stream) {
+    if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0,
+                                             stream, (const T*)dz, (const T*)u, mean, rstd, gamma, s1, s2, (T*)du,
+                                             dgamma, dbeta, M, C));
+    return istvt_check_launch();
+}
+
+// ============================================================================================
+// im2col / col2im for the two dense 3x3 convolutions (conv1: 3->32 s2 p0, conv2: 32->64 s1 p0)
+// column order is (dy, dx, ci): the GEMM weight is W.permute(0,2,3,1).reshape(Cout, 9*Cin)
+// ============================================================================================
+// conv1: x NCHW fp32 [Fr][3][S][S] -> col [Fr*Ho*Wo][32] (27 taps + 5 zero columns)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_c3s2_kernel(const float* __restrict__ x, T* __restrict__ col, long Mo,
+                                                          int S, int Ho, int Wo) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mo) return;
+    const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
+    const long f = m / ((long)Wo * Ho);
+    float v[32];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+                v[(dy * 3 + dx) * 3 + ci] = x[((f * 3 + ci) * S + 2 * yo + dy) * S + 2 * xo + dx];
+#pragma unroll
+    for (int i = 27; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v[c * 8 + i];
+        store8(col + m * 32 + c * 8, t);
+    }
+}
+
+// NHWC source, stride 1, pad 0, optional y = relu?(scale*x + shift) on load
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ src, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int relu,
+                                                        T* __restrict__ col, long Mo, int H, int W, int C, int Ho,
+                                                        int Wo) {
+    const int vpr = C / 8;
+    const long nitems = Mo * 9 * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+        const int ch = (int)(i % vpr);
+        const int tap = (int)((i / vpr) % 9);
+        const long m = i / (9 * vpr);
+        const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
+        const long f = m / ((long)Wo * Ho);
+        const int dy = tap / 3, dx = tap % 3;
+        float v[8];
+        load8(src + ((f * H + yo + dy) * W + xo + dx) * C + ch * 8, v);
+        if (scale) {
+            float sc[8], sh[8];
+            load8(scale + ch * 8, sc);
+            load8(shift + ch * 8, sh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        store8(col + m * 9 * C + tap * C + ch * 8, v);
+    }
+}
+
+// dx[f,yi,xi,c] = sum_{dy,dx} dcol[(f,yi-dy,xi-dx)][(dy,dx,c)], then masked by relu'(scale*u+shift)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ dcol, const T* __restrict__ u,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, T* __restrict__ dz, long Mi,
+                                                        int H, int W, int C, int Ho, int Wo) {
+    const int vpr = C / 8;
+    const long nitems = Mi * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+        const int ch = (int)(i % vpr);
+        const long m = i / vpr;
+        const int xi = (int)(m % W), yi = (int)((m / W) % H);
+        const long f = m / ((long)W * H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yo = yi - dy;
+            if (yo < 0 || yo >= Ho) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xo = xi - dx;
+                if (xo < 0 || xo >= Wo) continue;
+                float v[8];
+                load8(dcol + ((f * Ho + yo) * Wo + xo) * 9 * C + (dy * 3 + dx) * C + ch * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        }
+        if (u) {
+            float uv[8], sc[8], sh[8];
+            load8(u + m * C + ch * 8, uv);
+            load8(scale + ch * 8, sc);
+            load8(shift + ch * 8, sh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = (uv[j] * sc[j] + sh[j] > 0.f) ? acc[j] : 0.f;
+        }
+        store8(dz + m * C + ch * 8, acc);
+    }
+}
+
+extern "C" int istvt_im2col_conv1(const float* x, void* col, int Fr, int S, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || S < 3) return ISTVT_ERR_SHAPE;
+    const int Ho = (S - 3) / 2 + 1;
+    const long Mo = (long)Fr * Ho * Ho;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((im2col_c3s2_kernel<T>), dim3((unsigned)((Mo + 255) / 256)), dim3(256), 0,
+                                             stream, x, (T*)col, Mo, S, Ho, Ho));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_im2col3x3(const void* src, const float* scale, const float* shift, int relu, void* col, int Fr,
+                               int H, int W, int C, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || H < 3 || W < 3 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    const int Ho = H - 2, Wo = W - 2;
+    const long Mo = (long)Fr * Ho * Wo;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((im2col3x3_kernel<T>), dim3(ew_grid(Mo * 9 * (C / 8))), dim3(256), 0,
+                                             stream, (const T*)src, scale, shift, relu, (T*)col, Mo, H, W, C, Ho, Wo));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_col2im3x3(const void* dcol, const void* u, const float* scale, const float* shift, void* dz,
+                               int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || H < 3 || W < 3 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    const long Mi = (long)Fr * H * W;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col2im3x3_kernel<T>), dim3(ew_grid(Mi * (C / 8))), dim3(256), 0, stream,
+                                             (const T*)dcol, (const T*)u, scale, shift, (T*)dz, Mi, H, W, C, H - 2,
+                                             W - 2));
+    return istvt_check_launch();
+}
+
+// ============================================================================================
+// depthwise 3x3, stride 1, pad 1 (SeparableConv2d.conv1, xception.py:43) with an LDS tile
+// ============================================================================================
+constexpr int DW_TH = 8, DW_TW = 16, DW_CC = 32;            // output tile: 8 x 16 pixels x 32 channels
+constexpr int DW_LH = DW_TH + 2, DW_LW = DW_TW + 2;
+constexpr int DW_TILE_ELEMS = DW_LH * DW_LW * DW_CC;
+
+struct DwArgs {
+    const void* in; const float* w; void* out;
+    int Fr, H, W, C;
+    const float* in_scale; const float* in_shift; int in_relu;     // transform on load (forward)
+    int flip;                                                        // 1: correlate with flipped taps (input gradient)
+    const void* msrc; const float* m_scale; const float* m_shift;   // ReLU mask source (+ optional affine)
+    int mask_pre, mask_post;
+    const void* addsrc; int Ha, Wa;                                  // += addsrc[f][y/2][x/2] at even (y,x)
+    const float* st_mean; const float* st_rstd; double* st_s1; double* st_s2;   // fused BN-backward statistics
+};
+
+// load the (TH+2)x(TW+2)xCC input tile (zero outside the image; the on-load transform only
+// touches in-image pixels, i.e. the conv's zero padding is applied AFTER BN/ReLU as in the reference)
+template <typename T>
+__device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
+                                             int W, int C, const float* scale, const float* shift, int relu, int tid) {
+    constexpr int NVEC = DW_LH * DW_LW * (DW_CC / 8);
+    for (int i = tid; i < NVEC; i += 256) {
+        const int ch = i % (DW_CC / 8);
+        const int px = (i / (DW_CC / 8)) % DW_LW, py = i / ((DW_CC / 8) * DW_LW);
+        const int y = y0 - 1 + py, x = x0 - 1 + px, c = c0 + ch * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (y >= 0 && y < H && x >= 0 && x < W && c < C) {
+            load8(in + ((f * H + y) * W + x) * C + c, v);
+            if (scale) {
+                float sc[8], sh[8];
+                load8(scale + c, sc);
+                load8(shift + c, sh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+        }
+        store8(tile + (py * DW_LW + px) * DW_CC + ch * 8, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
+    __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
+    __shared__ float sred[2][4][DW_CC];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.W + DW_TW - 1) / DW_TW, tiles_y = (p.H + DW_TH - 1) / DW_TH;
+    const int t = blockIdx.x;
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+    const long f = t / (tiles_x * tiles_y);
+    const int c0 = blockIdx.y * DW_CC;
+    const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+    dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_scale, p.in_shift, p.in_relu, tid);
+
+    const int ch = tid & 3;                       // 8-channel chunk of this thread (same for both items)
+    const int c = c0 + ch * 8;
+    float wv[9][8];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int src_tap = p.flip ? 8 - tap : tap;
+            wv[tap][j] = (c + j < p.C) ? p.w[(long)(c + j) * 9 + src_tap] : 0.f;
+        }
+    __syncthreads();
+
+    float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int pix = (tid >> 2) + 64 * k;
+        const int py = pix / DW_TW, px = pix % DW_TW;
+        const int y = y0 + py, x = x0 + px;
+        if (y >= p.H || x >= p.W || c >= p.C) continue;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float v[8];
+                load8(tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j] * wv[dy * 3 + dx][j];
+            }
+        const long off = ((f * p.H + y) * p.W + x) * p.C + c;
+        // epilogue order: ReLU mask of the rep path (pre) -> add the skip-path gradient at the
+        // stride-2 positions -> ReLU mask that covers both paths (post)
+        float mv[8], z[8];
+        const bool have_m = p.msrc != nullptr;
+        if (have_m) {
+            load8((const T*)p.msrc + off, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = mv[j];
+            if (p.m_scale) {
+                float sc[8], sh[8];
+                load8(p.m_scale + c, sc);
+                load8(p.m_shift + c, sh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = z[j] * sc[j] + sh[j];
+            }
+        }
+        if (p.mask_pre) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = z[j] > 0.f ? acc[j] : 0.f;
+        }
+        if (p.addsrc && !(y & 1) && !(x & 1)) {
+            float a[8];
+            load8((const T*)p.addsrc + ((f * p.Ha + (y >> 1)) * p.Wa + (x >> 1)) * p.C + c, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += a[j];
+        }
+        if (p.mask_post) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = z[j] > 0.f ? acc[j] : 0.f;
+        }
+        if (p.st_s1 && have_m) {
+            // statistics of the (rounded) value that is stored, so they match a separate pass
+            float mu[8], rs[8];
+            load8(p.st_mean + c, mu);
+            load8(p.st_rstd + c, rs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = to_f32(from_f32<T>(acc[j]));
+                st1[j] += d;
+                st2[j] += d * (mv[j] - mu[j]) * rs[j];
+            }
+        }
+        store8((T*)p.out + off, acc);
+    }
+    if (p.st_s1) {
+        // reduce over the 16 pixels of a wave that share this channel chunk (lanes with equal tid&3)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {
+                st1[j] += __shfl_xor(st1[j], o, 64);
+                st2[j] += __shfl_xor(st2[j], o, 64);
+            }
+        }
+        const int lane = tid & 63, wid = tid >> 6;
+        if (lane < 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sred[0][wid][lane * 8 + j] = st1[j]; sred[1][wid][lane * 8 + j] = st2[j]; }
+        }
+        __syncthreads();
+        if (tid < DW_CC && c0 + tid < p.C) {
+            atomicAdd(p.st_s1 + c0 + tid, (double)(sred[0][0][tid] + sred[0][1][tid] + sred[0][2][tid] + sred[0][3][tid]));
+            atomicAdd(p.st_s2 + c0 + tid, (double)(sred[1][0][tid] + sred[1][1][tid] + sred[1][2][tid] + sred[1][3][tid]));
+        }
+    }
+}
+
+// dw[c][tap] += sum_pix dout[pix][c] * a[pix + tap][c],  a = on-load transform of the forward input
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ in, const float* in_scale,
+                                                              const float* in_shift, int in_relu,
+                                                              const T* __restrict__ dout, float* __restrict__ dw,
+                                                              int Fr, int H, int W, int C) {
+    __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
+    __shared__ float sred[4][4][72];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
+    const long ntiles = (long)Fr * tiles_x * tiles_y;
+    const int c0 = blockIdx.y * DW_CC;
+    const int ch = tid & 3, c = c0 + ch * 8;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const long f = t / (tiles_x * tiles_y);
+        const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+        __syncthreads();
+        dw_load_tile<T>(tile, in, f, y0, x0, c0, H, W, C, in_scale, in_shift, in_relu, tid);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pix = (tid >> 2) + 64 * k;
+            const int py = pix / DW_TW, px = pix % DW_TW;
+            const int y = y0 + py, x = x0 + px;
+            if (y >= H || x >= W || c >= C) continue;
+            float d[8];
+            load8(dout + ((f * H + y) * W + x) * C + c, d);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float v[8];
+                    load8(tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[dy * 3 + dx][j] += d[j] * v[j];
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) acc[t][j] += __shfl_xor(acc[t][j], o, 64);
+        }
+    const int lane = tid & 63, wid = tid >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sred[wid][lane][t * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int o = tid; o < 4 * 72; o += 256) {
+        const int chunk = o / 72, rem = o % 72, tap = rem / 8, j = rem % 8;
+        const int cc = c0 + chunk * 8 + j;
+        if (cc < C)
+            atomicAdd(dw + (long)cc * 9 + tap, sred[0][chunk][rem] + sred[1][chunk][rem] + sred[2][chunk][rem] + sred[3][chunk][rem]);
+    }
+}
+
+extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr, int H, int W, int C,
+                               const float* in_scale, const float* in_shift, int in_relu, int flip, const void* msrc,
+                               const float* m_scale, const float* m_shift, int mask_pre, int mask_post,
+                               const void* addsrc, int Ha, int Wa, const float* st_mean, const float* st_rstd,
+                               double* st_s1, double* st_s2, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    if ((mask_pre || mask_post || st_s1) && !msrc) return ISTVT_ERR_SHAPE;
+    if (addsrc && (Ha != (H - 1) / 2 + 1 || Wa != (W - 1) / 2 + 1)) return ISTVT_ERR_SHAPE;
+    DwArgs a;
+    a.in = in; a.w = w; a.out = out; a.Fr = Fr; a.H = H; a.W = W; a.C = C;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu; a.flip = flip;
+    a.msrc = msrc; a.m_scale = m_scale; a.m_shift = m_shift; a.mask_pre = mask_pre; a.mask_post = mask_post;
+    a.addsrc = addsrc; a.Ha = Ha; a.Wa = Wa; a.st_mean = st_mean; a.st_rstd = st_rstd; a.st_s1 = st_s1; a.st_s2 = st_s2;
+    const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
+    dim3 grid((unsigned)tiles, (C + DW_CC - 1) / DW_CC);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), grid, dim3(256), 0, stream, a));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_scale, const float* in_shift, int in_relu,
+                                     const void* dout, float* dw, int Fr, int H, int W, int C, int dtype,
+                                     hipStream_t stream) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
+    const int cy = (C + DW_CC - 1) / DW_CC;
+    long bx = 2048 / cy;
+    if (bx < 1) bx = 1;
+    if (bx > tiles) bx = tiles;
+    dim3 grid((unsigned)bx, cy);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, dim3(256), 0, stream, (const T*)in,
+                                             in_scale, in_shift, in_relu, (const T*)dout, dw, Fr, H, W, C));
+    return istvt_check_launch();
+}
+
+// ============================================================================================
+// MaxPool2d(3, 2, 1) fused with both BatchNorm applies and the skip add (Block.forward,
+// xception.py:88,91-100):   out = maxpool(bn(x)) + bn_skip(skip)
+// ============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__ x, const float* __restrict__ xs,
+                                                           const float* __restrict__ xb, const T* __restrict__ skip,
+                                                           const float* __restrict__ ss, const float* __restrict__ sb,
+                                                           T* __restrict__ out, uint8_t* __restrict__ argmax, long Mo,
+                                                           int H, int W, int C, int Ho, int Wo) {
+    const int vpr = C / 8;
+    const long nitems = Mo * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+        const int ch = (int)(i % vpr);
+        const long m = i / vpr;
+        const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
+        const long f = m / ((long)Wo * Ho);
+        float sc[8], sh[8];
+        load8(xs + ch * 8, sc);
+        load8(xb + ch * 8, sh);
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = 2 * yo - 1 + dy;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * xo - 1 + dx;
+                if (xx < 0 || xx >= W) continue;
+                float v[8];
+                load8(x + ((f * H + y) * W + xx) * C + ch * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = to_f32(from_f32<T>(v[j] * sc[j] + sh[j]));   // the value a separate BN pass would store
+                    if (z > best[j]) { best[j] = z; bi[j] = dy * 3 + dx; }       // first maximum wins (torch)
+                }
+            }
+        }
+        float sv[8], s2[8], b2[8];
+        load8(skip + m * C + ch * 8, sv);
+        load8(ss + ch * 8, s2);
+        load8(sb + ch * 8, b2);
+        uint64_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            best[j] += sv[j] * s2[j] + b2[j];
+            packed |= (uint64_t)bi[j] << (8 * j);
+        }
+        store8(out + m * C + ch * 8, best);
+        *reinterpret_cast<uint64_t*>(argmax + m * C + ch * 8) = packed;
+    }
+}
+
+// dz[f,y,x,c] = sum over the (<= 4) windows containing (y,x) of dout[window] * [argmax(window) == (y,x)]
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
+                                                       T* __restrict__ dz, long Mi, int H, int W, int C, int Ho,
+                                                       int Wo) {
+    const int vpr = C / 8;
+    const long nitems = Mi * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+        const int ch = (int)(i % vpr);
+        const long m = i / vpr;
+        const int x = (int)(m % W), y = (int)((m / W) % H);
+        const long f = m / ((long)W * H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int yo0 = y >> 1, xo0 = x >> 1;          // window yo covers rows 2yo-1 .. 2yo+1
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int yo = yo0 + a;
+            const int dy = y - (2 * yo - 1);
+            if (yo >= Ho || dy < 0 || dy > 2) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int xo = xo0 + b;
+                const int dx = x - (2 * xo - 1);
+                if (xo >= Wo || dx < 0 || dx > 2) continue;
+                const long mo = (f * Ho + yo) * Wo + xo;
+                const uint64_t packed = *reinterpret_cast<const uint64_t*>(argmax + mo * C + ch * 8);
+                float d[8];
+                load8(dout + mo * C + ch * 8, d);
+                const int want = dy * 3 + dx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if ((int)((packed >> (8 * j)) & 0xff) == want) acc[j] += d[j];
+            }
+        }
+        store8(dz + m * C + ch * 8, acc);
+    }
+}
+
+// out[f,yo,xo,:] = in[f,2yo,2xo,:]   (input of the stride-2 1x1 skip conv, xception.py:57)
+template <typename T>
+__global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ in, T* __restrict__ out, long Mo, int H,
+                                                         int W, int C, int Ho, int Wo) {
+    const int vpr = C / 8;
+    const long nitems = Mo * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+        const int ch = (int)(i % vpr);
+        const long m = i / vpr;
+        const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
+        const long f = m / ((long)Wo * Ho);
+        float v[8];
+        load8(in + ((f * H + 2 * yo) * W + 2 * xo) * C + ch * 8, v);
+        store8(out + m * C + ch * 8, v);
+    }
+}
+
+extern "C" int istvt_pool_add_fwd(const void* x, const float* xs, const float* xb, const void* skip, const float* ss,
+                                  const float* sb, void* out, uint8_t* argmax, int Fr, int H, int W, int C, int dtype,
+                                  hipStream_t stream) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long Mo = (long)Fr * Ho * Wo;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_add_fwd_kernel<T>), dim3(ew_grid(Mo * (C / 8))), dim3(256), 0,
+                                             stream, (const T*)x, xs, xb, (const T*)skip, ss, sb, (T*)out, argmax, Mo,
+                                             H, W, C, Ho, Wo));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_pool_bwd(const void* dout, const uint8_t* argmax, void* dz, int Fr, int H, int W, int C,
+                              int dtype, hipStream_t stream) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long Mi = (long)Fr * H * W;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(ew_grid(Mi * (C / 8))), dim3(256), 0, stream,
+                                             (const T*)dout, argmax, (T*)dz, Mi, H, W, C, Ho, Wo));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_subsample2(const void* in, void* out, int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long Mo = (long)Fr * Ho * Wo;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((subsample2_kernel<T>), dim3(ew_grid(Mo * (C / 8))), dim3(256), 0, stream,
+                                             (const T*)in, (T*)out, Mo, H, W, C, Ho, Wo));
+    return istvt_check_launch();
+}

@@ -140,16 +140,16 @@ class TemporalAttnFn(Function):
 
     @staticmethod
     def forward(ctx, qk, v, B, F, P, heads, dh):
-        out, lse = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
-        ctx.save_for_backward(qk, v, lse)
+        out = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
+        ctx.save_for_backward(qk, v)
         ctx.geom = (B, F, P, heads, dh)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        qk, v, lse = ctx.saved_tensors
-        dqk, dv = ops.attn_temporal_bwd(qk, v, dout, lse, *ctx.geom)
+        qk, v = ctx.saved_tensors
+        dqk, dv = ops.attn_temporal_bwd(qk, v, dout, *ctx.geom)
         return dqk, dv, None, None, None, None, None
 
 

@@ -211,7 +211,7 @@ def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int):
     if qkv.numel() != BF * P * 3 * inner:
         raise RuntimeError('attn_spatial: qkv %s is not (%d*%d, 3*%d)' % (tuple(qkv.shape), BF, P, inner))
     out = torch.empty((BF * P, inner), dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((BF * P, heads, 2), dtype=torch.float32, device=qkv.device)   # (row max [log2], 1/rowsum)
     _lib.check(_lib.lib().istvt_attn_spatial_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh,
                                                  dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_fwd')
     return out, lse
@@ -220,7 +220,7 @@ def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int):
 def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: int, P: int, heads: int, dh: int) -> Tensor:
     dout = _c(_req(dout))
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
+    delta = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.lib().istvt_attn_spatial_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
                                                  delta.data_ptr(), dqkv.data_ptr(), BF, P, heads, dh, dh ** -0.5,
                                                  dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
@@ -235,18 +235,17 @@ def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int,
     if qk.numel() != B * F * P * 2 * inner or v.numel() != B * F * P * inner:
         raise RuntimeError('attn_temporal: shapes %s / %s do not match B=%d F=%d P=%d' % (tuple(qk.shape), tuple(v.shape), B, F, P))
     out = torch.empty((B * F * P, inner), dtype=qk.dtype, device=qk.device)
-    lse = torch.empty((B * F * P, heads), dtype=torch.float32, device=qk.device)
-    _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), B, F, P,
+    _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), v.data_ptr(), out.data_ptr(), B, F, P,
                                                   heads, dh, dh ** -0.5, dtype_code(qk), _stream()),
                'istvt_attn_temporal_fwd')
-    return out, lse
+    return out
 
 
-def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, lse: Tensor, B: int, F: int, P: int, heads: int, dh: int):
+def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: int, heads: int, dh: int):
     dout = _c(_req(dout))
     dqk = torch.empty_like(qk)
     dv = torch.empty_like(v)
-    _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), v.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+    _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), v.data_ptr(), dout.data_ptr(),
                                                   dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
                                                   dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
     return dqk, dv

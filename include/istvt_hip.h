@@ -59,7 +59,8 @@ int istvt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const fl
                         int F, int P, int dtype, istvt_stream_t stream);
 
 /* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
- * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)'), out [BF*P][heads*dh], lse [BF*P][heads]. */
+ * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)'), out [BF*P][heads*dh],
+ * lse [BF*P][heads][2] = softmax statistics (row max in the log2 domain, 1/row sum). */
 int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh, float scale,
                            int dtype, istvt_stream_t stream);
 int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta_scratch,
@@ -68,10 +69,10 @@ int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, c
 
 /* ---- temporal attention (TemporalResidualAttention.forward core, module.py:197-205) --------
  * qk [B*F*P][2*heads*dh] (q|k), v/out [B*F*P][heads*dh], rows (b,f,p); F <= 17. */
-int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, float* lse, int B, int F, int P, int heads,
-                            int dh, float scale, int dtype, istvt_stream_t stream);
-int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, const float* lse, void* dqk, void* dv,
-                            int B, int F, int P, int heads, int dh, float scale, int dtype, istvt_stream_t stream);
+int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, int B, int F, int P, int heads, int dh,
+                            float scale, int dtype, istvt_stream_t stream);
+int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int B, int F, int P,
+                            int heads, int dh, float scale, int dtype, istvt_stream_t stream);
 
 /* ---- token assembly (DSTTr.forward, vivit.py:133-142) -------------------------------------- */
 int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, int B,

@@ -51,7 +51,9 @@ def gemm_exact(dtype, mode, M=200, N=136, K=104):
         dy, x = ints((M, N), dtype, 5), ints((M, K), dtype, 6)
         y = ops.linear_wgrad(dy, x)
         ref = dy.double().t() @ x.double()
-    return float((y.double() - ref).abs().max()), 0.0
+    if mode != 'wgrad':
+        ref = ref.to(dtype)            # the exact sum, rounded once to the storage type
+    return float((y.double() - ref.double()).abs().max()), 0.0
 
 
 def gemm_real(dtype, mode):
@@ -160,7 +162,7 @@ def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64):
     inner = heads * dh
     M = B * F * P
     qk, v = rnd((M, 2 * inner), dtype, 1), rnd((M, inner), dtype, 2)
-    out, lse = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
+    out = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
     qkd, vd = qk.double().requires_grad_(True), v.double().requires_grad_(True)
 
     def split(t):                                    # (b f p) (h d) -> b h p f d
@@ -169,7 +171,7 @@ def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64):
     ref = _attn_ref(q, k, split(vd)).permute(0, 3, 2, 1, 4).reshape(M, inner)
     dout = rnd((M, inner), dtype, 3)
     ref.backward(dout.double())
-    dqk, dv = ops.attn_temporal_bwd(qk, v, dout, lse, B, F, P, heads, dh)
+    dqk, dv = ops.attn_temporal_bwd(qk, v, dout, B, F, P, heads, dh)
     e = max(relerr(out, ref), relerr(dqk, qkd.grad), relerr(dv, vd.grad))
     return e, TOL[dtype]
 
