@@ -25,6 +25,20 @@ SIGNATURES = {
     'istvt_tokens_fwd': [P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_tokens_bwd': [P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],
+    'istvt_bn_stats': [P, P, P, L, I, I, P],
+    'istvt_bn_finalize': [P, P, ctypes.c_double, P, P, P, P, F, F, P, I, I, I, P],
+    'istvt_bn_apply': [P, P, P, L, I, I, I, P],
+    'istvt_bn_bwd_stats': [P, P, P, P, P, L, I, I, P],
+    'istvt_bn_bwd_apply': [P, P, P, P, P, P, P, P, P, L, I, I, P],
+    'istvt_im2col_conv1': [P, P, I, I, I, P],
+    'istvt_col2im_conv1': [P, P, I, I, I, P],
+    'istvt_im2col3x3': [P, P, I, P, I, I, I, I, I, P],
+    'istvt_col2im3x3': [P, P, P, P, I, I, I, I, I, P],
+    'istvt_dwconv3x3': [P, P, P, I, I, I, I, P, I, I, P, P, I, I, P, I, I, P, P, I, P],
+    'istvt_dwconv3x3_wgrad': [P, P, I, P, P, I, I, I, I, I, P],
+    'istvt_pool_add_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
+    'istvt_pool_bwd': [P, P, P, I, I, I, I, I, P],
+    'istvt_subsample2': [P, P, I, I, I, I, I, P],
     'istvt_colsum': [P, P, L, I, L, I, P],
     'istvt_cast': [P, I, P, I, L, P],
 }

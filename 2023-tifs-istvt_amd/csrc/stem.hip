@@ -15,6 +15,19 @@
 // All of these are HBM-bound (AI <= 4.5 flop/B): coalesced 16-byte accesses along C.
 #include "common.h"
 
+// A finalized BatchNorm is passed around as ONE pointer `bnp` to a float [4][C] pack:
+//   row 0 mean, row 1 rstd, row 2 scale = gamma * rstd, row 3 beta.
+// Consumers apply it in the centred form  z = (u - mean) * scale + beta  (NOT u*scale + shift:
+// with |mean| >> std the folded shift loses ~eps*|mean|/std and flips ReLU masks near zero).
+__device__ __forceinline__ void bn_affine8(float (&v)[8], const float* bnp, int C, int c) {
+    float mu[8], sc[8], be[8];
+    load8(bnp + c, mu);
+    load8(bnp + 2 * C + c, sc);
+    load8(bnp + 3 * C + c, be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu[j]) * sc[j] + be[j];
+}
+
 // ============================================================================================
 // column reductions over a [M][C] matrix, C % 8 == 0
 // ============================================================================================
@@ -78,9 +91,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 // s1[c] += sum_m dz ; s2[c] += sum_m dz * xhat,  xhat = (u - mean) * rstd
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ dz, const T* __restrict__ u,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, double* s1, double* s2,
+                                                           const float* __restrict__ bnp, double* s1, double* s2,
                                                            long M, int C, int rpb) {
+    const float* mean = bnp;
+    const float* rstd = bnp + C;
     double* const outs[2] = {s1, s2};
     colreduce_block<2>([&](long m, int c0, float (&acc)[2][8]) {
         float d[8], uv[8], mu[8], rs[8];
@@ -93,12 +107,11 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     }, outs, M, C, rpb);
 }
 
-// finalize: batch (use_batch=1) or running statistics -> mean, rstd, scale = g*rstd, shift = b - mean*scale;
+// finalize: batch (use_batch=1) or running statistics -> pack {mean, rstd, scale = g*rstd, beta};
 // updates running stats like torch (momentum, unbiased variance) when update_running.
 __global__ void bn_finalize_kernel(const double* sum, const double* sumsq, double count, const float* gamma,
                                    const float* beta, float* rmean, float* rvar, float momentum, float eps,
-                                   float* mean_o, float* rstd_o, float* scale_o, float* shift_o, int C, int use_batch,
-                                   int update_running) {
+                                   float* bnp, int C, int use_batch, int update_running) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double mean, var;
@@ -117,29 +130,26 @@ __global__ void bn_finalize_kernel(const double* sum, const double* sumsq, doubl
     }
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * rstd;
-    mean_o[c] = (float)mean;
-    rstd_o[c] = rstd;
-    scale_o[c] = sc;
-    shift_o[c] = beta[c] - (float)mean * sc;
+    bnp[c] = (float)mean;
+    bnp[C + c] = rstd;
+    bnp[2 * C + c] = sc;
+    bnp[3 * C + c] = beta[c];
 }
 
-// y = x * scale + shift (optionally ReLU)
+// y = (x - mean) * scale + beta (optionally ReLU)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, T* __restrict__ y, long M,
-                                                       int C, int relu) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ bnp,
+                                                       T* __restrict__ y, long M, int C, int relu) {
     const int vpr = C / 8;
     const long nvec = M * vpr, stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
         const int c0 = (int)(i % vpr) * 8;
-        float v[8], sc[8], sh[8];
+        float v[8];
         load8(x + i * 8, v);
-        load8(scale + c0, sc);
-        load8(shift + c0, sh);
+        bn_affine8(v, bnp, C, c0);
+        if (relu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = v[j] * sc[j] + sh[j];
-            if (relu) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         store8(y + i * 8, v);
     }
@@ -150,14 +160,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 // from the masked dz, so the mask is applied by the producer instead; kept out of this kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ u,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ bnp,
                                                            const float* __restrict__ gamma, const double* s1,
                                                            const double* s2, T* __restrict__ du, float* dgamma,
                                                            float* dbeta, long M, int C) {
     const int vpr = C / 8;
     const long nvec = M * vpr, stride = (long)gridDim.x * 256;
     const float invM = 1.0f / (float)M;
+    const float* mean = bnp;
+    const float* rstd = bnp + C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
         const int c0 = (int)(i % vpr) * 8;
         float d[8], uv[8], mu[8], rs[8], g[8];
@@ -197,39 +208,38 @@ extern "C" int istvt_bn_stats(const void* x, double* sum, double* sumsq, long M,
 }
 
 extern "C" int istvt_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma,
-                                 const float* beta, float* rmean, float* rvar, float momentum, float eps, float* mean,
-                                 float* rstd, float* scale, float* shift, int C, int use_batch, int update_running,
-                                 hipStream_t stream) {
+                                 const float* beta, float* rmean, float* rvar, float momentum, float eps, float* bnp,
+                                 int C, int use_batch, int update_running, hipStream_t stream) {
     if (C <= 0) return ISTVT_ERR_SHAPE;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sum, sumsq, count, gamma, beta,
-                       rmean, rvar, momentum, eps, mean, rstd, scale, shift, C, use_batch, update_running);
+                       rmean, rvar, momentum, eps, bnp, C, use_batch, update_running);
     return istvt_check_launch();
 }
 
-extern "C" int istvt_bn_apply(const void* x, const float* scale, const float* shift, void* y, long M, int C, int relu,
-                              int dtype, hipStream_t stream) {
+extern "C" int istvt_bn_apply(const void* x, const float* bnp, void* y, long M, int C, int relu, int dtype,
+                              hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0, stream,
-                                             (const T*)x, scale, shift, (T*)y, M, C, relu));
+                                             (const T*)x, bnp, (T*)y, M, C, relu));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_bn_bwd_stats(const void* dz, const void* u, const float* mean, const float* rstd, double* s1,
-                                  double* s2, long M, int C, int dtype, hipStream_t stream) {
+extern "C" int istvt_bn_bwd_stats(const void* dz, const void* u, const float* bnp, double* s1, double* s2, long M,
+                                  int C, int dtype, hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     dim3 grid; int rpb;
     colreduce_grid(M, C, grid, rpb);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), grid, dim3(256), 0, stream, (const T*)dz,
-                                             (const T*)u, mean, rstd, s1, s2, M, C, rpb));
+                                             (const T*)u, bnp, s1, s2, M, C, rpb));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_bn_bwd_apply(const void* dz, const void* u, const float* mean, const float* rstd,
+extern "C" int istvt_bn_bwd_apply(const void* dz, const void* u, const float* bnp,
                                   const float* gamma, const double* s1, const double* s2, void* du, float* dgamma,
                                   float* dbeta, long M, int C, int dtype, hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0,
-                                             stream, (const T*)dz, (const T*)u, mean, rstd, gamma, s1, s2, (T*)du,
+                                             stream, (const T*)dz, (const T*)u, bnp, gamma, s1, s2, (T*)du,
                                              dgamma, dbeta, M, C));
     return istvt_check_launch();
 }
@@ -265,12 +275,11 @@ __global__ __launch_bounds__(256) void im2col_c3s2_kernel(const float* __restric
     }
 }
 
-// NHWC source, stride 1, pad 0, optional y = relu?(scale*x + shift) on load
+// NHWC source, stride 1, pad 0, optional BatchNorm pack (+ReLU) applied on load
 template <typename T>
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ src, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, int relu,
-                                                        T* __restrict__ col, long Mo, int H, int W, int C, int Ho,
-                                                        int Wo) {
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ src, const float* __restrict__ bnp,
+                                                        int relu, T* __restrict__ col, long Mo, int H, int W, int C,
+                                                        int Ho, int Wo) {
     const int vpr = C / 8;
     const long nitems = Mo * 9 * vpr, stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
@@ -282,13 +291,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ sr
         const int dy = tap / 3, dx = tap % 3;
         float v[8];
         load8(src + ((f * H + yo + dy) * W + xo + dx) * C + ch * 8, v);
-        if (scale) {
-            float sc[8], sh[8];
-            load8(scale + ch * 8, sc);
-            load8(shift + ch * 8, sh);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
-        }
+        if (bnp) bn_affine8(v, bnp, C, ch * 8);
         if (relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -297,11 +300,10 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ sr
     }
 }
 
-// dx[f,yi,xi,c] = sum_{dy,dx} dcol[(f,yi-dy,xi-dx)][(dy,dx,c)], then masked by relu'(scale*u+shift)
+// dx[f,yi,xi,c] = sum_{dy,dx} dcol[(f,yi-dy,xi-dx)][(dy,dx,c)], then masked by relu'(bn(u))
 template <typename T>
 __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ dcol, const T* __restrict__ u,
-                                                        const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, T* __restrict__ dz, long Mi,
+                                                        const float* __restrict__ bnp, T* __restrict__ dz, long Mi,
                                                         int H, int W, int C, int Ho, int Wo) {
     const int vpr = C / 8;
     const long nitems = Mi * vpr, stride = (long)gridDim.x * 256;
@@ -326,15 +328,48 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ dc
             }
         }
         if (u) {
-            float uv[8], sc[8], sh[8];
+            float uv[8];
             load8(u + m * C + ch * 8, uv);
-            load8(scale + ch * 8, sc);
-            load8(shift + ch * 8, sh);
+            bn_affine8(uv, bnp, C, ch * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = (uv[j] * sc[j] + sh[j] > 0.f) ? acc[j] : 0.f;
+            for (int j = 0; j < 8; ++j) acc[j] = (uv[j] > 0.f) ? acc[j] : 0.f;
         }
         store8(dz + m * C + ch * 8, acc);
     }
+}
+
+// conv1 input gradient (only needed when the clip itself requires grad): NCHW fp32
+// dx[f][ci][y][x] = sum_{dy,dx} dcol[(f,(y-dy)/2,(x-dx)/2)][(dy*3+dx)*3+ci] over even offsets in range
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_c3s2_kernel(const T* __restrict__ dcol, float* __restrict__ dx, long n,
+                                                          int S, int Ho, int Wo) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % S), y = (int)((i / S) % S);
+    const int ci = (int)((i / ((long)S * S)) % 3);
+    const long f = i / ((long)3 * S * S);
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int t = y - dy;
+        if (t < 0 || (t & 1) || (t >> 1) >= Ho) continue;
+#pragma unroll
+        for (int dxx = 0; dxx < 3; ++dxx) {
+            const int s = x - dxx;
+            if (s < 0 || (s & 1) || (s >> 1) >= Wo) continue;
+            acc += to_f32(dcol[((f * Ho + (t >> 1)) * Wo + (s >> 1)) * 32 + (dy * 3 + dxx) * 3 + ci]);
+        }
+    }
+    dx[i] = acc;
+}
+
+extern "C" int istvt_col2im_conv1(const void* dcol, float* dx, int Fr, int S, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || S < 3) return ISTVT_ERR_SHAPE;
+    const int Ho = (S - 3) / 2 + 1;
+    const long n = (long)Fr * 3 * S * S;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col2im_c3s2_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                             stream, (const T*)dcol, dx, n, S, Ho, Ho));
+    return istvt_check_launch();
 }
 
 extern "C" int istvt_im2col_conv1(const float* x, void* col, int Fr, int S, int dtype, hipStream_t stream) {
@@ -346,22 +381,22 @@ extern "C" int istvt_im2col_conv1(const float* x, void* col, int Fr, int S, int 
     return istvt_check_launch();
 }
 
-extern "C" int istvt_im2col3x3(const void* src, const float* scale, const float* shift, int relu, void* col, int Fr,
-                               int H, int W, int C, int dtype, hipStream_t stream) {
+extern "C" int istvt_im2col3x3(const void* src, const float* bnp, int relu, void* col, int Fr, int H, int W, int C,
+                               int dtype, hipStream_t stream) {
     if (Fr <= 0 || H < 3 || W < 3 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const int Ho = H - 2, Wo = W - 2;
     const long Mo = (long)Fr * Ho * Wo;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((im2col3x3_kernel<T>), dim3(ew_grid(Mo * 9 * (C / 8))), dim3(256), 0,
-                                             stream, (const T*)src, scale, shift, relu, (T*)col, Mo, H, W, C, Ho, Wo));
+                                             stream, (const T*)src, bnp, relu, (T*)col, Mo, H, W, C, Ho, Wo));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_col2im3x3(const void* dcol, const void* u, const float* scale, const float* shift, void* dz,
-                               int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
+extern "C" int istvt_col2im3x3(const void* dcol, const void* u, const float* bnp, void* dz, int Fr, int H, int W,
+                               int C, int dtype, hipStream_t stream) {
     if (Fr <= 0 || H < 3 || W < 3 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const long Mi = (long)Fr * H * W;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((col2im3x3_kernel<T>), dim3(ew_grid(Mi * (C / 8))), dim3(256), 0, stream,
-                                             (const T*)dcol, (const T*)u, scale, shift, (T*)dz, Mi, H, W, C, H - 2,
+                                             (const T*)dcol, (const T*)u, bnp, (T*)dz, Mi, H, W, C, H - 2,
                                              W - 2));
     return istvt_check_launch();
 }
@@ -376,19 +411,19 @@ constexpr int DW_TILE_ELEMS = DW_LH * DW_LW * DW_CC;
 struct DwArgs {
     const void* in; const float* w; void* out;
     int Fr, H, W, C;
-    const float* in_scale; const float* in_shift; int in_relu;     // transform on load (forward)
+    const float* in_bn; int in_relu;                                 // BatchNorm pack (+ReLU) applied on load
     int flip;                                                        // 1: correlate with flipped taps (input gradient)
-    const void* msrc; const float* m_scale; const float* m_shift;   // ReLU mask source (+ optional affine)
+    const void* msrc; const float* m_bn;                             // ReLU mask source (+ optional BatchNorm pack)
     int mask_pre, mask_post;
     const void* addsrc; int Ha, Wa;                                  // += addsrc[f][y/2][x/2] at even (y,x)
-    const float* st_mean; const float* st_rstd; double* st_s1; double* st_s2;   // fused BN-backward statistics
+    double* st_s1; double* st_s2;                                    // fused BN-backward statistics (of m_bn)
 };
 
 // load the (TH+2)x(TW+2)xCC input tile (zero outside the image; the on-load transform only
 // touches in-image pixels, i.e. the conv's zero padding is applied AFTER BN/ReLU as in the reference)
 template <typename T>
 __device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
-                                             int W, int C, const float* scale, const float* shift, int relu, int tid) {
+                                             int W, int C, const float* bnp, int relu, int tid) {
     constexpr int NVEC = DW_LH * DW_LW * (DW_CC / 8);
     for (int i = tid; i < NVEC; i += 256) {
         const int ch = i % (DW_CC / 8);
@@ -397,13 +432,7 @@ __device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, 
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (y >= 0 && y < H && x >= 0 && x < W && c < C) {
             load8(in + ((f * H + y) * W + x) * C + c, v);
-            if (scale) {
-                float sc[8], sh[8];
-                load8(scale + c, sc);
-                load8(shift + c, sh);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
-            }
+            if (bnp) bn_affine8(v, bnp, C, c);
             if (relu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -424,7 +453,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     const long f = t / (tiles_x * tiles_y);
     const int c0 = blockIdx.y * DW_CC;
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
-    dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_scale, p.in_shift, p.in_relu, tid);
+    dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
 
     const int ch = tid & 3;                       // 8-channel chunk of this thread (same for both items)
     const int c = c0 + ch * 8;
@@ -464,13 +493,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
             load8((const T*)p.msrc + off, mv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = mv[j];
-            if (p.m_scale) {
-                float sc[8], sh[8];
-                load8(p.m_scale + c, sc);
-                load8(p.m_shift + c, sh);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = z[j] * sc[j] + sh[j];
-            }
+            if (p.m_bn) bn_affine8(z, p.m_bn, p.C, c);
         }
         if (p.mask_pre) {
 #pragma unroll
@@ -489,8 +512,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         if (p.st_s1 && have_m) {
             // statistics of the (rounded) value that is stored, so they match a separate pass
             float mu[8], rs[8];
-            load8(p.st_mean + c, mu);
-            load8(p.st_rstd + c, rs);
+            load8(p.m_bn + c, mu);
+            load8(p.m_bn + p.C + c, rs);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = to_f32(from_f32<T>(acc[j]));
@@ -525,8 +548,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 
 // dw[c][tap] += sum_pix dout[pix][c] * a[pix + tap][c],  a = on-load transform of the forward input
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ in, const float* in_scale,
-                                                              const float* in_shift, int in_relu,
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ in, const float* in_bn,
+                                                              int in_relu,
                                                               const T* __restrict__ dout, float* __restrict__ dw,
                                                               int Fr, int H, int W, int C) {
     __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
         const long f = t / (tiles_x * tiles_y);
         const int y0 = ty * DW_TH, x0 = tx * DW_TW;
         __syncthreads();
-        dw_load_tile<T>(tile, in, f, y0, x0, c0, H, W, C, in_scale, in_shift, in_relu, tid);
+        dw_load_tile<T>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -591,27 +614,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 }
 
 extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr, int H, int W, int C,
-                               const float* in_scale, const float* in_shift, int in_relu, int flip, const void* msrc,
-                               const float* m_scale, const float* m_shift, int mask_pre, int mask_post,
-                               const void* addsrc, int Ha, int Wa, const float* st_mean, const float* st_rstd,
-                               double* st_s1, double* st_s2, int dtype, hipStream_t stream) {
+                               const float* in_bn, int in_relu, int flip, const void* msrc, const float* m_bn,
+                               int mask_pre, int mask_post, const void* addsrc, int Ha, int Wa, double* st_s1,
+                               double* st_s2, int dtype, hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     if ((mask_pre || mask_post || st_s1) && !msrc) return ISTVT_ERR_SHAPE;
+    if (st_s1 && !m_bn) return ISTVT_ERR_SHAPE;
     if (addsrc && (Ha != (H - 1) / 2 + 1 || Wa != (W - 1) / 2 + 1)) return ISTVT_ERR_SHAPE;
     DwArgs a;
     a.in = in; a.w = w; a.out = out; a.Fr = Fr; a.H = H; a.W = W; a.C = C;
-    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu; a.flip = flip;
-    a.msrc = msrc; a.m_scale = m_scale; a.m_shift = m_shift; a.mask_pre = mask_pre; a.mask_post = mask_post;
-    a.addsrc = addsrc; a.Ha = Ha; a.Wa = Wa; a.st_mean = st_mean; a.st_rstd = st_rstd; a.st_s1 = st_s1; a.st_s2 = st_s2;
+    a.in_bn = in_bn; a.in_relu = in_relu; a.flip = flip;
+    a.msrc = msrc; a.m_bn = m_bn; a.mask_pre = mask_pre; a.mask_post = mask_post;
+    a.addsrc = addsrc; a.Ha = Ha; a.Wa = Wa; a.st_s1 = st_s1; a.st_s2 = st_s2;
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
     dim3 grid((unsigned)tiles, (C + DW_CC - 1) / DW_CC);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), grid, dim3(256), 0, stream, a));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_scale, const float* in_shift, int in_relu,
-                                     const void* dout, float* dw, int Fr, int H, int W, int C, int dtype,
-                                     hipStream_t stream) {
+extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw,
+                                     int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
     const int cy = (C + DW_CC - 1) / DW_CC;
@@ -620,7 +642,7 @@ extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_scale, cons
     if (bx > tiles) bx = tiles;
     dim3 grid((unsigned)bx, cy);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, dim3(256), 0, stream, (const T*)in,
-                                             in_scale, in_shift, in_relu, (const T*)dout, dw, Fr, H, W, C));
+                                             in_bn, in_relu, (const T*)dout, dw, Fr, H, W, C));
     return istvt_check_launch();
 }
 
@@ -629,9 +651,8 @@ extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_scale, cons
 // xception.py:88,91-100):   out = maxpool(bn(x)) + bn_skip(skip)
 // ============================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__ x, const float* __restrict__ xs,
-                                                           const float* __restrict__ xb, const T* __restrict__ skip,
-                                                           const float* __restrict__ ss, const float* __restrict__ sb,
+__global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bnx,
+                                                           const T* __restrict__ skip, const float* __restrict__ bns,
                                                            T* __restrict__ out, uint8_t* __restrict__ argmax, long Mo,
                                                            int H, int W, int C, int Ho, int Wo) {
     const int vpr = C / 8;
@@ -641,9 +662,6 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
         const long m = i / vpr;
         const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
         const long f = m / ((long)Wo * Ho);
-        float sc[8], sh[8];
-        load8(xs + ch * 8, sc);
-        load8(xb + ch * 8, sh);
         float best[8];
         int bi[8];
 #pragma unroll
@@ -658,21 +676,21 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
                 if (xx < 0 || xx >= W) continue;
                 float v[8];
                 load8(x + ((f * H + y) * W + xx) * C + ch * 8, v);
+                bn_affine8(v, bnx, C, ch * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float z = to_f32(from_f32<T>(v[j] * sc[j] + sh[j]));   // the value a separate BN pass would store
+                    const float z = to_f32(from_f32<T>(v[j]));                   // the value a separate BN pass would store
                     if (z > best[j]) { best[j] = z; bi[j] = dy * 3 + dx; }       // first maximum wins (torch)
                 }
             }
         }
-        float sv[8], s2[8], b2[8];
+        float sv[8];
         load8(skip + m * C + ch * 8, sv);
-        load8(ss + ch * 8, s2);
-        load8(sb + ch * 8, b2);
+        bn_affine8(sv, bns, C, ch * 8);
         uint64_t packed = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            best[j] += sv[j] * s2[j] + b2[j];
+            best[j] += sv[j];
             packed |= (uint64_t)bi[j] << (8 * j);
         }
         store8(out + m * C + ch * 8, best);
@@ -735,14 +753,13 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ i
     }
 }
 
-extern "C" int istvt_pool_add_fwd(const void* x, const float* xs, const float* xb, const void* skip, const float* ss,
-                                  const float* sb, void* out, uint8_t* argmax, int Fr, int H, int W, int C, int dtype,
-                                  hipStream_t stream) {
+extern "C" int istvt_pool_add_fwd(const void* x, const float* bnx, const void* skip, const float* bns, void* out,
+                                  uint8_t* argmax, int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long Mo = (long)Fr * Ho * Wo;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_add_fwd_kernel<T>), dim3(ew_grid(Mo * (C / 8))), dim3(256), 0,
-                                             stream, (const T*)x, xs, xb, (const T*)skip, ss, sb, (T*)out, argmax, Mo,
+                                             stream, (const T*)x, bnx, (const T*)skip, bns, (T*)out, argmax, Mo,
                                              H, W, C, Ho, Wo));
     return istvt_check_launch();
 }

@@ -71,3 +71,29 @@ class DSTTr(nn.Module):
         """x: (b, t, c, h, w) as in the reference (vivit.py:132)."""
         b, t, c, h, w = x.shape
         return self.forward_features(x.flatten(3).transpose(2, 3).contiguous())
+
+
+class XceptionVidTr(nn.Module):
+    """Reference: vivit.py:193-208.  ``XceptionVidTr()`` reproduces the reference exactly
+    (6 frames, 19x19 grid from 300^2 crops, depth 12); the keyword arguments generalise the
+    geometry it hard-codes."""
+
+    def __init__(self, *, num_frames=6, grid=19, depth=12, dim=728, heads=8, dim_head=64, scale_dim=4,
+                 num_classes=1, compute_dtype=torch.float32):
+        super(XceptionVidTr, self).__init__()
+        from ..models import model_selection
+        self.xcep = model_selection(modelname='xception', num_out_classes=2, dropout=0.5, batch_size=1)
+        self.vit = DSTTr(grid, 1, num_classes, num_frames, dim=dim, depth=depth, heads=heads, dim_head=dim_head,
+                         scale_dim=scale_dim, compute_dtype=compute_dtype)
+        self.compute_dtype = compute_dtype
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+        self.vit.compute_dtype = dtype
+        return self
+
+    def forward(self, x):
+        b, t = x.shape[:2]
+        feats = self.xcep.model.low_level_features_nhwc(x.flatten(0, 1), self.compute_dtype)   # (b*t, h, w, c)
+        n, h, w, c = feats.shape
+        return self.vit.forward_features(feats.view(b, t, h * w, c))

@@ -45,7 +45,7 @@ def _stream() -> int:
 
 # ------------------------------------------------------------------------------------------
 # fp32 master weight -> compute-dtype operand, cached per parameter version
-_wcache: 'weakref.WeakKeyDictionary[Tensor, Tuple[int, Tensor]]' = weakref.WeakKeyDictionary()
+_wcache: dict = {}
 
 
 def cast(t: Tensor, dtype: torch.dtype) -> Tensor:
@@ -68,15 +68,21 @@ def weight_as(w: Tensor, dtype: torch.dtype) -> Tensor:
         w2 = w2.reshape(w2.shape[0], -1)
     if w2.dtype == dtype:
         return _c(w2)
-    hit = _wcache.get(w)
-    if hit is not None and hit[0] == w._version and hit[1].dtype == dtype:
-        return hit[1]
+    key = id(w)                       # id-keyed: Tensor.__eq__ is elementwise, so tensors cannot be dict keys
+    hit = _wcache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].dtype == dtype:
+        return hit[2]
     out = cast(w2, dtype)
-    _wcache[w] = (w._version, out)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)
     return out
 
 
 # ------------------------------------------------------------------------------------------
+# bench.py sets this to a list to time every GEMM launch with events on the launch stream:
+# entries are (start_event, end_event, algorithmic_flops, (a_kc, b_kc), (M, N, K)).
+gemm_profile = None
+
+
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
              C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0):
@@ -85,9 +91,16 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
         raise TypeError('gemm operands must share a dtype (%s vs %s)' % (A.dtype, B.dtype))
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError('bias must be float32')
+    prof = gemm_profile
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = _lib.lib().istvt_gemm(A.data_ptr(), lda, int(a_kc), B.data_ptr(), ldb, int(b_kc), C.data_ptr(), ldc, M, N, K,
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
                                dtype_code(A), _stream())
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K)))
     _lib.check(rc, 'istvt_gemm')
 
 

@@ -1,0 +1,343 @@
+"""Xception entry flow (conv1 .. block3, reference network/xception.py:193-206) as one
+autograd Function whose forward and backward are sequences of HIP launches.
+
+Layout: activations are NHWC ``[frames, H, W, C]`` in the compute dtype, so the stem's output
+``[B*T, h, w, 728]`` already is the transformer's ``(b, t, h*w, c)`` token layout (no permute).
+
+Fusion plan: train-mode BatchNorm needs a grid-wide reduction, so every BN is
+split into {statistics kernel -> tiny finalize kernel} and its apply(+ReLU) is folded into the
+consumer's load: the depthwise conv's LDS tile load, conv2's im2col, or the maxpool+skip-add
+kernel.  Only bn2's output is materialised (it has two consumers).  In backward the ReLU masks,
+the stride-2 scatter of the skip-path gradient and the BN-backward reductions ride in the
+depthwise input-gradient kernel's epilogue.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib, ops
+from .ops import _c, _ptr, _req, _stream, dtype_code
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def out_side(side: int) -> int:
+    s = (side - 3) // 2 + 1 - 2
+    for _ in range(3):
+        s = (s - 1) // 2 + 1
+    return s
+
+
+# ------------------------------------------------------------------------------------------ launch wrappers
+class BNState:
+    """Per-BatchNorm statistics produced by the forward and reused by the backward."""
+    __slots__ = ('pack', 'mean', 'rstd', 'scale', 'beta')
+
+    def __init__(self, C, device):
+        # one [4][C] pack {mean, rstd, scale = gamma*rstd, beta}: kernels take its base pointer and
+        # apply z = (u - mean) * scale + beta
+        self.pack = torch.empty((4, C), dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.beta = self.pack[0], self.pack[1], self.pack[2], self.pack[3]
+
+    def ptr(self):
+        return self.pack.data_ptr()
+
+
+def bn_forward_stats(u: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor,
+                     training: bool) -> BNState:
+    st = BNState(C, u.device)
+    L = _lib.lib()
+    if training:
+        acc = torch.zeros((2, C), dtype=torch.float64, device=u.device)
+        _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), M, C, dtype_code(u), _stream()),
+                   'istvt_bn_stats')
+        s0, s1 = acc[0].data_ptr(), acc[1].data_ptr()
+    else:
+        s0 = s1 = None
+    _lib.check(L.istvt_bn_finalize(s0, s1, float(M), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
+                                   BN_MOMENTUM, BN_EPS, st.ptr(), C, int(training), int(training), _stream()),
+               'istvt_bn_finalize')
+    return st
+
+
+def bn_apply(u: Tensor, st: BNState, M: int, C: int, relu: bool) -> Tensor:
+    y = torch.empty_like(u)
+    _lib.check(_lib.lib().istvt_bn_apply(u.data_ptr(), st.ptr(), y.data_ptr(), M, C, int(relu), dtype_code(u), _stream()),
+               'istvt_bn_apply')
+    return y
+
+
+def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: int, stats: Optional[Tensor] = None):
+    """-> (du, dgamma, dbeta).  `stats` = [2][C] fp64 sums already accumulated by a fused producer."""
+    L = _lib.lib()
+    if stats is None:
+        stats = torch.zeros((2, C), dtype=torch.float64, device=u.device)
+        _lib.check(L.istvt_bn_bwd_stats(dz.data_ptr(), u.data_ptr(), st.ptr(),
+                                        stats[0].data_ptr(), stats[1].data_ptr(), M, C, dtype_code(u), _stream()),
+                   'istvt_bn_bwd_stats')
+    du = torch.empty_like(u)
+    dg = torch.zeros((C,), dtype=torch.float32, device=u.device)
+    db = torch.zeros((C,), dtype=torch.float32, device=u.device)
+    _lib.check(L.istvt_bn_bwd_apply(dz.data_ptr(), u.data_ptr(), st.ptr(), gamma.data_ptr(),
+                                    stats[0].data_ptr(), stats[1].data_ptr(), du.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                    M, C, dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
+    return du, dg, db
+
+
+def dwconv(x: Tensor, w9: Tensor, Fr: int, H: int, W: int, C: int, *, in_bn: Optional[BNState] = None,
+           in_relu: bool = False, flip: bool = False, msrc: Optional[Tensor] = None, m_bn: Optional[BNState] = None,
+           mask_pre: bool = False, mask_post: bool = False, addsrc: Optional[Tensor] = None,
+           stats: Optional[Tensor] = None) -> Tensor:
+    """stats ([2][C] fp64, accumulated): fused BatchNorm-backward sums of the OUTPUT w.r.t. `m_bn`."""
+    out = torch.empty((Fr * H * W, C), dtype=x.dtype, device=x.device)
+    Ha, Wa = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    _lib.check(_lib.lib().istvt_dwconv3x3(
+        x.data_ptr(), w9.data_ptr(), out.data_ptr(), Fr, H, W, C,
+        in_bn.ptr() if in_bn else None, int(in_relu), int(flip),
+        _ptr(msrc), m_bn.ptr() if m_bn else None, int(mask_pre), int(mask_post),
+        _ptr(addsrc), Ha, Wa,
+        stats[0].data_ptr() if stats is not None else None, stats[1].data_ptr() if stats is not None else None,
+        dtype_code(x), _stream()), 'istvt_dwconv3x3')
+    return out
+
+
+def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn: Optional[BNState], in_relu: bool) -> Tensor:
+    dw = torch.zeros((C, 9), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().istvt_dwconv3x3_wgrad(x.data_ptr(), in_bn.ptr() if in_bn else None, int(in_relu), dout.data_ptr(),
+                                                dw.data_ptr(), Fr, H, W, C, dtype_code(x), _stream()),
+               'istvt_dwconv3x3_wgrad')
+    return dw
+
+
+def _conv1_weight(w: Tensor, dtype) -> Tensor:
+    """(32,3,3,3) [co][ci][dy][dx] -> [co][(dy,dx,ci) padded to 32] in the compute dtype."""
+    w2 = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 27)
+    w2 = torch.nn.functional.pad(w2, (0, 5))
+    return ops.cast(w2.contiguous(), dtype)
+
+
+def _conv2_weight(w: Tensor, dtype) -> Tensor:
+    return ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), dtype)
+
+
+# ------------------------------------------------------------------------------------------ the Function
+BLOCKS = (('block1', 64, 128, False), ('block2', 128, 256, True), ('block3', 256, 728, True))
+# parameter order of StemFn.apply (after x): see param_names()
+
+
+def param_names() -> List[str]:
+    """State-dict names (relative to the Xception module) of the parameters on the path, in
+    the order StemFn expects them."""
+    names = ['conv1.weight', 'bn1.weight', 'bn1.bias', 'conv2.weight', 'bn2.weight', 'bn2.bias']
+    for name, cin, cout, relu in BLOCKS:
+        i0 = 1 if relu else 0
+        names += ['%s.skip.weight' % name, '%s.skipbn.weight' % name, '%s.skipbn.bias' % name,
+                  '%s.rep.%d.conv1.weight' % (name, i0), '%s.rep.%d.pointwise.weight' % (name, i0),
+                  '%s.rep.%d.weight' % (name, i0 + 1), '%s.rep.%d.bias' % (name, i0 + 1),
+                  '%s.rep.%d.conv1.weight' % (name, i0 + 3), '%s.rep.%d.pointwise.weight' % (name, i0 + 3),
+                  '%s.rep.%d.weight' % (name, i0 + 4), '%s.rep.%d.bias' % (name, i0 + 4)]
+    return names
+
+
+def bn_names() -> List[str]:
+    """BatchNorm module names in the order their (running_mean, running_var) buffers are passed."""
+    names = ['bn1', 'bn2']
+    for name, cin, cout, relu in BLOCKS:
+        i0 = 1 if relu else 0
+        names += ['%s.skipbn' % name, '%s.rep.%d' % (name, i0 + 1), '%s.rep.%d' % (name, i0 + 4)]
+    return names
+
+
+class StemFn(Function):
+    """y = Xception.low_level_features(x).  x: (Fr,3,S,S) float32 NCHW; y: (Fr,h,w,728) NHWC in
+    `dtype`.  `buffers` = [running_mean, running_var] * 11 in bn_names() order (updated in place
+    when training)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, training, buffers, *params):
+        _req(x, 'input clip')
+        if x.dtype != torch.float32:
+            raise TypeError('stem input must be float32, got %s' % x.dtype)
+        x = _c(x)
+        Fr, cin, S, S2 = x.shape
+        if cin != 3 or S != S2:
+            raise RuntimeError('stem expects (frames, 3, S, S) input, got %s' % (tuple(x.shape),))
+        L = _lib.lib()
+        dev = x.device
+        P = dict(zip(param_names(), params))
+        bufs = {n: (buffers[2 * i], buffers[2 * i + 1]) for i, n in enumerate(bn_names())}
+        sv = {}                                             # everything backward needs
+
+        def bn(name, u, M, C):
+            rm, rv = bufs[name]
+            return bn_forward_stats(u, M, C, P[name + '.weight'], P[name + '.bias'], rm, rv, training)
+
+        # conv1 (3->32, 3x3, s2, p0) as im2col + GEMM
+        H1 = (S - 3) // 2 + 1
+        M1 = Fr * H1 * H1
+        col1 = torch.empty((M1, 32), dtype=dtype, device=dev)
+        _lib.check(L.istvt_im2col_conv1(x.data_ptr(), col1.data_ptr(), Fr, S, ops._DT[dtype], _stream()), 'istvt_im2col_conv1')
+        w1 = _conv1_weight(P['conv1.weight'], dtype)
+        u1 = ops.linear_fwd(col1, w1)
+        del col1
+        bn1 = bn('bn1', u1, M1, 32)
+        # conv2 (32->64, 3x3, p0): im2col applies bn1 + ReLU on load
+        H2 = H1 - 2
+        M2 = Fr * H2 * H2
+        col2 = torch.empty((M2, 288), dtype=dtype, device=dev)
+        _lib.check(L.istvt_im2col3x3(u1.data_ptr(), bn1.ptr(), 1, col2.data_ptr(), Fr, H1, H1, 32, ops._DT[dtype], _stream()),
+                   'istvt_im2col3x3')
+        w2 = _conv2_weight(P['conv2.weight'], dtype)
+        u2 = ops.linear_fwd(col2, w2)
+        del col2
+        bn2 = bn('bn2', u2, M2, 64)
+        a2 = bn_apply(u2, bn2, M2, 64, True)
+        sv.update(x=x, S=S, Fr=Fr, H1=H1, H2=H2, u1=u1, bn1=bn1, u2=u2, bn2=bn2, w1=w1, w2=w2)
+
+        X, H = a2, H2
+        blocks = []
+        for name, cin_, cout, pre_relu in BLOCKS:
+            i0 = 1 if pre_relu else 0
+            M = Fr * H * H
+            Hs = (H - 1) // 2 + 1
+            Ms = Fr * Hs * Hs
+            wdwA = P['%s.rep.%d.conv1.weight' % (name, i0)].detach().reshape(cin_, 9)
+            wpwA = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0)], dtype)
+            wdwB = P['%s.rep.%d.conv1.weight' % (name, i0 + 3)].detach().reshape(cout, 9)
+            wpwB = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0 + 3)], dtype)
+            wsk = ops.weight_as(P[name + '.skip.weight'], dtype)
+            d1 = dwconv(X, wdwA, Fr, H, H, cin_, in_relu=pre_relu)
+            uA = ops.linear_fwd(d1, wpwA)
+            bnA = bn('%s.rep.%d' % (name, i0 + 1), uA, M, cout)
+            d2 = dwconv(uA, wdwB, Fr, H, H, cout, in_bn=bnA, in_relu=True)
+            uB = ops.linear_fwd(d2, wpwB)
+            bnB = bn('%s.rep.%d' % (name, i0 + 4), uB, M, cout)
+            xs = torch.empty((Ms, cin_), dtype=dtype, device=dev)
+            _lib.check(L.istvt_subsample2(X.data_ptr(), xs.data_ptr(), Fr, H, H, cin_, ops._DT[dtype], _stream()),
+                       'istvt_subsample2')
+            uS = ops.linear_fwd(xs, wsk)
+            bnS = bn(name + '.skipbn', uS, Ms, cout)
+            out = torch.empty((Ms, cout), dtype=dtype, device=dev)
+            amax = torch.empty((Ms, cout), dtype=torch.uint8, device=dev)
+            _lib.check(L.istvt_pool_add_fwd(uB.data_ptr(), bnB.ptr(), uS.data_ptr(), bnS.ptr(), out.data_ptr(),
+                                            amax.data_ptr(), Fr, H, H, cout, ops._DT[dtype], _stream()), 'istvt_pool_add_fwd')
+            blocks.append(dict(name=name, i0=i0, cin=cin_, cout=cout, pre_relu=pre_relu, H=H, Hs=Hs, X=X, d1=d1, uA=uA,
+                               bnA=bnA, d2=d2, uB=uB, bnB=bnB, xs=xs, uS=uS, bnS=bnS, amax=amax, wdwA=wdwA, wpwA=wpwA,
+                               wdwB=wdwB, wpwB=wpwB, wsk=wsk))
+            X, H = out, Hs
+        sv['blocks'] = blocks
+        sv['P'] = P
+        sv['training'] = training
+        sv['dtype'] = dtype
+        ctx.sv = sv
+        ctx.need_dx = x.requires_grad
+        return X.view(Fr, H, H, 728)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        sv = ctx.sv
+        if not sv['training']:
+            raise NotImplementedError('backward through the stem in eval() mode (running-stat BatchNorm) is not implemented')
+        L = _lib.lib()
+        P, Fr, dtype = sv['P'], sv['Fr'], sv['dtype']
+        dtc = ops._DT[dtype]
+        grads = {}
+        dOut = _c(dy).reshape(-1, 728)
+        for blk in reversed(sv['blocks']):
+            name, i0, cin, cout, H, Hs = blk['name'], blk['i0'], blk['cin'], blk['cout'], blk['H'], blk['Hs']
+            M, Ms = Fr * H * H, Fr * Hs * Hs
+            dev = dOut.device
+            # skip path: skipbn -> 1x1 stride-2 conv
+            duS, dg, db = bn_backward(dOut, blk['uS'], blk['bnS'], P[name + '.skipbn.weight'], Ms, cout)
+            grads[name + '.skipbn.weight'], grads[name + '.skipbn.bias'] = dg, db
+            grads[name + '.skip.weight'] = ops.linear_wgrad(duS, blk['xs'])
+            dxs = ops.linear_dgrad(duS, blk['wsk'])
+            # rep path: maxpool -> BN_B -> pointwise_B -> depthwise_B -> ReLU -> BN_A -> pointwise_A -> depthwise_A
+            dzB = torch.empty((M, cout), dtype=dtype, device=dev)
+            _lib.check(L.istvt_pool_bwd(dOut.data_ptr(), blk['amax'].data_ptr(), dzB.data_ptr(), Fr, H, H, cout, dtc,
+                                        _stream()), 'istvt_pool_bwd')
+            nB = '%s.rep.%d' % (name, i0 + 4)
+            duB, dg, db = bn_backward(dzB, blk['uB'], blk['bnB'], P[nB + '.weight'], M, cout)
+            grads[nB + '.weight'], grads[nB + '.bias'] = dg, db
+            del dzB
+            sB = '%s.rep.%d' % (name, i0 + 3)
+            grads[sB + '.pointwise.weight'] = ops.linear_wgrad(duB, blk['d2'])
+            dd2 = ops.linear_dgrad(duB, blk['wpwB'])
+            del duB
+            grads[sB + '.conv1.weight'] = dwconv_wgrad(blk['uA'], dd2, Fr, H, H, cout, blk['bnA'], True)
+            statsA = torch.zeros((2, cout), dtype=torch.float64, device=dev)
+            dzA = dwconv(dd2, blk['wdwB'], Fr, H, H, cout, flip=True, msrc=blk['uA'], m_bn=blk['bnA'], mask_pre=True,
+                         stats=statsA)
+            del dd2
+            nA = '%s.rep.%d' % (name, i0 + 1)
+            duA, dg, db = bn_backward(dzA, blk['uA'], blk['bnA'], P[nA + '.weight'], M, cout, stats=statsA)
+            grads[nA + '.weight'], grads[nA + '.bias'] = dg, db
+            del dzA
+            sA = '%s.rep.%d' % (name, i0)
+            grads[sA + '.pointwise.weight'] = ops.linear_wgrad(duA, blk['d1'])
+            dd1 = ops.linear_dgrad(duA, blk['wpwA'])
+            del duA
+            grads[sA + '.conv1.weight'] = dwconv_wgrad(blk['X'], dd1, Fr, H, H, cin, None, blk['pre_relu'])
+            if blk['pre_relu']:
+                # d(block input) = relu'(X) * d(rep path) + scatter(d skip path)
+                dOut = dwconv(dd1, blk['wdwA'], Fr, H, H, cin, flip=True, msrc=blk['X'], mask_pre=True, addsrc=dxs)
+            else:
+                # block1: its input is relu(bn2(u2)); fold that ReLU mask and bn2's backward statistics in
+                stats2 = torch.zeros((2, cin), dtype=torch.float64, device=dev)
+                dOut = dwconv(dd1, blk['wdwA'], Fr, H, H, cin, flip=True, msrc=sv['u2'], m_bn=sv['bn2'], mask_post=True,
+                              addsrc=dxs, stats=stats2)
+            del dd1
+        # bn2 -> conv2
+        H1, H2, S = sv['H1'], sv['H2'], sv['S']
+        M1, M2 = Fr * H1 * H1, Fr * H2 * H2
+        du2, dg, db = bn_backward(dOut, sv['u2'], sv['bn2'], P['bn2.weight'], M2, 64, stats=stats2)
+        grads['bn2.weight'], grads['bn2.bias'] = dg, db
+        col2 = torch.empty((M2, 288), dtype=dtype, device=du2.device)
+        _lib.check(L.istvt_im2col3x3(sv['u1'].data_ptr(), sv['bn1'].ptr(), 1, col2.data_ptr(), Fr, H1, H1, 32, dtc, _stream()),
+                   'istvt_im2col3x3')
+        dW2 = ops.linear_wgrad(du2, col2)                                    # [64][(dy,dx,ci)]
+        grads['conv2.weight'] = dW2.view(64, 3, 3, 32).permute(0, 3, 1, 2).contiguous()
+        dcol2 = ops.linear_dgrad(du2, sv['w2'])
+        del du2, col2
+        dz1 = torch.empty((M1, 32), dtype=dtype, device=dcol2.device)
+        _lib.check(L.istvt_col2im3x3(dcol2.data_ptr(), sv['u1'].data_ptr(), sv['bn1'].ptr(), dz1.data_ptr(), Fr, H1, H1, 32,
+                                     dtc, _stream()),
+                   'istvt_col2im3x3')
+        del dcol2
+        du1, dg, db = bn_backward(dz1, sv['u1'], sv['bn1'], P['bn1.weight'], M1, 32)
+        grads['bn1.weight'], grads['bn1.bias'] = dg, db
+        del dz1
+        col1 = torch.empty((M1, 32), dtype=dtype, device=du1.device)
+        _lib.check(L.istvt_im2col_conv1(sv['x'].data_ptr(), col1.data_ptr(), Fr, S, dtc, _stream()), 'istvt_im2col_conv1')
+        dW1 = ops.linear_wgrad(du1, col1)                                    # [32][32]
+        grads['conv1.weight'] = dW1[:, :27].reshape(32, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        dx = None
+        if ctx.need_dx:
+            dcol1 = ops.linear_dgrad(du1, sv['w1'])
+            dx = torch.empty_like(sv['x'])
+            _lib.check(L.istvt_col2im_conv1(dcol1.data_ptr(), dx.data_ptr(), Fr, S, dtc, _stream()), 'istvt_col2im_conv1')
+        ctx.sv = None
+        out = [grads[n].view(P[n].shape) for n in param_names()]
+        return (dx, None, None, None, *out)
+
+
+def stem_forward(x: Tensor, xcep: torch.nn.Module, dtype: torch.dtype) -> Tensor:
+    """Run the HIP stem with the parameters/buffers of an ``Xception`` module (network/xception.py)."""
+    named = dict(xcep.named_parameters())
+    bufs = dict(xcep.named_buffers())
+    params = [named[n] for n in param_names()]
+    buffers = []
+    for n in bn_names():
+        buffers += [bufs[n + '.running_mean'], bufs[n + '.running_var']]
+    y = StemFn.apply(x, dtype, xcep.training, buffers, *params)
+    if xcep.training:
+        for n in bn_names():
+            bufs[n + '.num_batches_tracked'] += 1
+    return y

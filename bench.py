@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the ISTVT hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): per GPU B=32 clips x T=8 frames x 3x224x224, full
+ISTVT (Xception stem + 12-layer decomposed spatial-temporal transformer), bf16 activation
+storage / fp32 accumulate, one full training step = zero grads -> forward -> BCE loss ->
+backward -> (N>1: one RCCL all-reduce of the flat gradient bucket) -> SGD-momentum step, on
+synthetic data with random-init weights, inputs resident in HBM.  Weak scaling: the per-GPU batch
+is fixed, so `value` = N * B * K / max-over-ranks(time).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MFMA GEMM: 97 % of
+the model's FLOPs): algorithmic FLOPs of its launches / their duration measured with events on
+the launch stream in an instrumented extra step.  `cpu_baseline` times the oracle (the CPU
+restatement of the reference, parity-pinned to it) on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+GF_PER_CLIP_FWD_BWD = {8: 1021.1, 16: 1938.7}     # SURVEY.md 8(a), T=8 / T=16 at 224^2, depth 12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=8)
+    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--depth', type=int, default=12)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, size, depth):
+    """oracle (kind "port"): one fwd+bwd of ONE clip of the benchmark geometry on the host cores."""
+    from oracle import istvt_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    grid = R.stem_out_side(size)
+    shapes = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
+    shapes.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(frames, grid, depth=depth).items()})
+    p = R.with_grad(R.random_params(shapes, seed=0))
+    x = torch.randn((1, frames, 3, size, size), generator=torch.Generator().manual_seed(0))
+    labels = torch.ones(1)
+    t0 = time.perf_counter()
+    logits = R.xception_vidtr_forward(p, x, depth=depth)
+    R.bce_with_logits(logits, labels).backward()
+    dt = time.perf_counter() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 clip (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads, %.1f s'
+                      % (frames, size, size, depth, torch.get_num_threads(), dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    elif a.gpus > 1:
+        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local_rank)
+
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import ops, parallel
+    from istvt_amd import stem as stem_mod
+    from istvt_amd.network.vivit.vivit import XceptionVidTr
+
+    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    grid = stem_mod.out_side(a.size)
+    torch.manual_seed(0)                       # identical init on every rank (+ broadcast below)
+    model = XceptionVidTr(num_frames=a.frames, grid=grid, depth=a.depth, compute_dtype=dtype).to(dev).train()
+    parallel.broadcast_parameters(model)
+    live = [p for _, p in parallel.live_named_parameters(model)]
+    bucket = parallel.GradBucket(live)
+    opt = torch.optim.SGD(live, lr=1e-3, momentum=0.9, weight_decay=0)     # train_CNN.py:200
+    crit = torch.nn.BCEWithLogitsLoss()                                      # train_CNN.py:148
+
+    g = torch.Generator(device='cpu').manual_seed(1 + rank)
+    x = torch.randn((a.batch, a.frames, 3, a.size, a.size), generator=g).to(dev)
+    labels = (torch.rand((a.batch,), generator=g) > 0.5).float().to(dev)
+
+    def step():
+        bucket.zero()
+        logits = model(x)
+        loss = crit(logits.view(-1), labels)
+        loss.backward()
+        bucket.all_reduce()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
+    roof = None
+    if rank == 0 and not a.no_kernel_profile:
+        ops.gemm_profile = []
+        step()
+        torch.cuda.synchronize(dev)
+        recs, ops.gemm_profile = ops.gemm_profile, None
+        by = {}
+        for ev0, ev1, flops, variant, shape in recs:
+            d = by.setdefault(variant, [0.0, 0.0, 0])
+            d[0] += flops
+            d[1] += ev0.elapsed_time(ev1) * 1e-3
+            d[2] += 1
+        tot_f = sum(d[0] for d in by.values())
+        tot_t = sum(d[1] for d in by.values())
+        n = sum(d[2] for d in by.values())
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        ach = tot_f / tot_t / 1e12
+        names = {(True, True): 'fwd(NT)', (True, False): 'dgrad(NN)', (False, False): 'wgrad(TN)'}
+        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<%s> (all Linear / 1x1-conv / im2col-conv GEMMs)' % a.dtype,
+                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': None, 'launches': n, 'avg_launch_us': round(tot_t / n * 1e6, 2),
+                'algorithmic_gflop_per_launch': round(tot_f / n / 1e9, 3), 'gemm_time_ms_per_step': round(tot_t * 1e3, 3),
+                'by_variant': {names[k]: {'tflops': round(v[0] / v[1] / 1e12, 2), 'ms': round(v[1] * 1e3, 3), 'launches': v[2]}
+                               for k, v in by.items()}}
+
+    if rank == 0:
+        clips = world * a.batch * a.steps
+        value = clips / elapsed
+        out = {
+            'metric': 'clips/sec (BxTx3x224x224 fwd+bwd)', 'value': round(value, 3), 'unit': 'clips/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if dtype == torch.bfloat16 else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: B=%d/GPU T=%d %dx%d full ISTVT (Xception stem + %d-layer DSTTr) train step '
+                                   '(fwd+bwd+grad all-reduce+SGD), random-init weights' % (a.batch, a.frames, a.size, a.size, a.depth),
+                       'global_batch': world * a.batch, 'frames': a.frames, 'size': a.size, 'depth': a.depth,
+                       'parallelism': 'dp%d' % world, 'loss': round(loss_val, 5)},
+        }
+        gf = GF_PER_CLIP_FWD_BWD.get(a.frames) if (a.size == 224 and a.depth == 12) else None
+        if gf:
+            out['model_tflops_per_gpu'] = round(value / world * gf / 1e3, 2)
+            out['model_mfma_frac'] = round(value / world * gf / 1e3 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS), 4)
+        if roof:
+            out['roofline'] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

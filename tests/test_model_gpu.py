@@ -1,0 +1,144 @@
+"""End-to-end parity of the HIP model on a real MI355X.
+
+* G5: the reference-native configuration (XceptionVidTr(), T=6, 300^2 -> 19x19, depth 12) against
+  the golden vector captured from the reference itself: logit, BCE loss, every live gradient
+  norm, one SGD step.
+* C1 / 224^2 geometries (which the reference cannot run) against the
+  oracle, which is pinned to the reference at grid 19 and differs only by the integer P.
+Tolerances (float32 parity mode): logits rtol 1e-3 (BASELINE.json north_star); gradient norms
+2e-2 (a few ReLU/maxpool decisions at |z| ~ 1e-6 land differently under another fp32 summation
+order and each moves early stem gradients by O(1e-3..1e-2), see DESIGN.md "Parity").
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import recipe  # noqa: E402
+
+
+def _load():
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network.vivit.vivit import XceptionVidTr
+    from istvt_amd.network.models import model_selection
+    return XceptionVidTr, model_selection
+
+
+def relerr(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b), dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def load_recipe(model):
+    sd = model.state_dict()
+    model.load_state_dict({k: torch.from_numpy(recipe.param_value(k, tuple(v.shape))) for k, v in sd.items()})
+    return model.cuda().train()
+
+
+def test_g5_native_end_to_end_hip(golden_dir):
+    XceptionVidTr, model_selection = _load()
+    g = np.load(os.path.join(golden_dir, 'G5_native.npz'))
+    model = load_recipe(model_selection('resnet_3d', 1, dropout=0.5, batch_size=1))     # the CLI name of the path
+    assert isinstance(model, XceptionVidTr)
+    x = torch.from_numpy(recipe.input_value('g5.x', (1, 6, 3, 300, 300))).cuda()
+    labels = torch.ones(1, device='cuda')
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=0)
+    opt.zero_grad()
+    logits = model(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits.view(-1), labels.float())
+    loss.backward()
+    assert logits.shape == (1, 1) and logits.dtype == torch.float32
+    assert relerr(logits, g['logits']) < 1e-3
+    assert relerr(loss, g['loss']) < 1e-2            # loss = softplus(-logit): d loss / loss amplifies d logit
+    live = [str(s) for s in g['live_param_names']]
+    named = dict(model.named_parameters())
+    got = sorted(k for k, p in named.items() if p.grad is not None)
+    assert got == sorted(live)                        # the 19.7 M dead Xception params get no gradient
+    worst = max((relerr(named[k].grad.norm(), g['gnorm.' + k]), k) for k in live)
+    assert worst[0] < 2e-2, worst
+    for k in g.files:
+        if k.startswith('grad.'):
+            assert relerr(named[k[5:]].grad.reshape(-1)[:64], g[k]) < 2e-2, k
+    opt.step()
+    for k in g.files:
+        if k.startswith('after_sgd.'):
+            assert relerr(named[k[len('after_sgd.'):]].reshape(-1)[:64], g[k]) < 1e-5, k
+    sd = model.state_dict()
+    assert relerr(sd['xcep.model.bn1.running_mean'], g['bn1.running_mean']) < 1e-4
+    assert relerr(sd['xcep.model.bn1.running_var'], g['bn1.running_var']) < 1e-4
+    assert int(sd['xcep.model.bn1.num_batches_tracked']) == 1
+
+
+def _oracle_case(B, T, side, depth, seed=0):
+    from oracle import istvt_ref as R
+    grid = R.stem_out_side(side)
+    shapes = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
+    shapes.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(T, grid, depth=depth).items()})
+    p = R.random_params(shapes, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn((B, T, 3, side, side), generator=g)
+    labels = (torch.rand((B,), generator=g) > 0.5).float()
+    return R, p, x, labels, grid
+
+
+def _hip_model(p, T, grid, depth, dtype=torch.float32):
+    XceptionVidTr, _ = _load()
+    model = XceptionVidTr(num_frames=T, grid=grid, depth=depth, compute_dtype=dtype)
+    sd = model.state_dict()
+    sd.update(p)
+    model.load_state_dict(sd)
+    return model.cuda().train()
+
+
+def test_c1_forward_vs_oracle():
+    """BASELINE.json configs[0]: 1 clip, T=4, 96x96, stem + 2-layer ISTVT, forward."""
+    R, p, x, labels, grid = _oracle_case(1, 4, 96, 2)
+    assert grid == 6
+    with torch.no_grad():
+        ref = R.xception_vidtr_forward({k: v.clone() for k, v in p.items()}, x, depth=2)
+    model = _hip_model(p, 4, grid, 2)
+    with torch.no_grad():
+        out = model(x.cuda())
+    assert relerr(out, ref) < 1e-3
+
+
+@pytest.mark.parametrize('T', [8, 16])
+def test_224_fwd_bwd_vs_oracle(T):
+    """C2/C4 geometry (224^2 -> 14x14 grid, F = 9 / 17 frames) at reduced batch/depth."""
+    R, p, x, labels, grid = _oracle_case(2, T, 224, 2)
+    assert grid == 14
+    pr = R.with_grad(p)
+    ref = R.xception_vidtr_forward(pr, x, depth=2)
+    R.bce_with_logits(ref, labels).backward()
+    model = _hip_model(p, T, grid, 2)
+    out = model(x.cuda())
+    torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+    assert relerr(out, ref) < 1e-3
+    named = dict(model.named_parameters())
+    errs = sorted(((relerr(named[k].grad.norm(), v.grad.norm()), k) for k, v in pr.items()
+                   if v.requires_grad and v.grad is not None), reverse=True)
+    assert errs[0][0] < 2e-2, errs[:5]
+    dirs = sorted(((relerr(named[k].grad, v.grad), k) for k, v in pr.items()
+                   if v.requires_grad and v.grad is not None and k.startswith('vit.')), reverse=True)
+    assert dirs[0][0] < 2e-2, dirs[:5]
+
+
+def test_bf16_mode_tracks_fp32():
+    """bfloat16 throughput mode: same weights, logits within the tolerance the survey measured for
+    bf16 autocast of this model (~1e-2 relative at random init; asserted at 5e-2)."""
+    R, p, x, labels, grid = _oracle_case(2, 8, 224, 2)
+    m32 = _hip_model(p, 8, grid, 2)
+    with torch.no_grad():
+        y32 = m32(x.cuda())
+    m16 = _hip_model(p, 8, grid, 2, dtype=torch.bfloat16)
+    y16 = m16(x.cuda())
+    torch.nn.functional.binary_cross_entropy_with_logits(y16.view(-1), labels.cuda()).backward()
+    assert y16.dtype == torch.float32
+    assert float((y16.detach() - y32).abs().max() / y32.abs().max().clamp_min(1e-3)) < 5e-2
+    assert all(torch.isfinite(q.grad).all() for q in m16.parameters() if q.grad is not None)

@@ -23,6 +23,8 @@ for name, fn in gpu_checks.all_checks():
         ok = err <= tol and err == err
         bad += not ok
         print('%-44s err %.3e tol %.1e %s (%.2fs)' % (name, err, tol, 'ok' if ok else 'FAIL', time.time() - t), flush=True)
+        if name.startswith('stem_oracle'):
+            print('    worst:', ['%s=%.2e' % kv for kv in gpu_checks.stem_vs_oracle.last], flush=True)
     except Exception as e:  # noqa: BLE001
         bad += 1
         print('%-44s EXC %s' % (name, repr(e)[:300]), flush=True)
