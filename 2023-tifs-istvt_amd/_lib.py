@@ -39,6 +39,7 @@ SIGNATURES = {
     'istvt_pool_add_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
     'istvt_pool_bwd': [P, P, P, I, I, I, I, I, P],
     'istvt_subsample2': [P, P, I, I, I, I, I, P],
+    'istvt_splitk_reduce': [P, I, L, P, P],
     'istvt_colsum': [P, P, L, I, L, I, P],
     'istvt_cast': [P, I, P, I, L, P],
 }

@@ -31,6 +31,7 @@ struct GemmArgs {
     int kper;             // K range per blockIdx.z
     int a_vec, b_vec;     // 16-byte vector loads legal for the operand
     float alpha;
+    long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -39,6 +40,8 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
     return cdf + u * pdf;
 }
+
+#include "gemm256.h"
 
 template <typename T> struct Tile { static constexpr int BK = 32; };
 template <> struct Tile<bf16_t> { static constexpr int BK = 64; };
@@ -196,51 +199,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         for (int nt = 0; nt < 4; ++nt) {
             const int n = bn0 + wn * 64 + nt * 16 + 4 * g;
             if (n >= p.N) continue;
-            float v[4] = {acc[mt][nt][0] * p.alpha, acc[mt][nt][1] * p.alpha, acc[mt][nt][2] * p.alpha,
-                          acc[mt][nt][3] * p.alpha};
-            const int nv = min(4, p.N - n);
-            if (p.bias && blockIdx.z == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j];
-            }
-            if (p.atomic_f32) {
-                float* c = (float*)p.C + (long)m * p.ldc + n;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (j < nv) atomicAdd(c + j, v[j]);
-                continue;
-            }
-            const long off = (long)m * p.ldc + n;
-            if (p.epi == EPI_GELU_FWD) {
-                float gv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gv[j] = gelu_f(v[j]);
-                T* c = (T*)p.C + off;
-                T* c2 = (T*)p.C2 + off;
-                if (nvec) { store4(c, v); store4(c2, gv); }
-                else { for (int j = 0; j < nv; ++j) { c[j] = from_f32<T>(v[j]); c2[j] = from_f32<T>(gv[j]); } }
-                continue;
-            }
-            if (p.epi == EPI_GELU_BWD) {
-                const T* u = (const T*)p.C2 + off;
-                float uv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nvec) load4(u, uv); else { for (int j = 0; j < nv; ++j) uv[j] = to_f32(u[j]); }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(uv[j]);
-            }
-            if (p.residual) {
-                const T* rp = (const T*)p.residual + (long)m * p.ldr + n;
-                float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nvec && (p.ldr % 4 == 0)) load4(rp, rv); else { for (int j = 0; j < nv; ++j) rv[j] = to_f32(rp[j]); }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += rv[j];
-            }
-            if (p.out_f32) {
-                float* c = (float*)p.C + off;
-                if (nvec) store4(c, v); else { for (int j = 0; j < nv; ++j) c[j] = v[j]; }
-            } else {
-                T* c = (T*)p.C + off;
-                if (nvec) store4(c, v); else { for (int j = 0; j < nv; ++j) c[j] = from_f32<T>(v[j]); }
-            }
+            gemm_epilogue4<T>(p, m, n, acc[mt][nt], nvec);
         }
     }
 }
@@ -260,21 +219,58 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                           int M, int N, int K, const float* bias, const void* residual, long ldr, void* C2, int epi,
                           int out_mode, int splitk, float alpha, int dtype, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return ISTVT_ERR_SHAPE;
-    if (out_mode < 0 || out_mode > 2 || epi < 0 || epi > 2) return ISTVT_ERR_SHAPE;
+    if (out_mode < 0 || out_mode > 3 || epi < 0 || epi > 2) return ISTVT_ERR_SHAPE;
     if (splitk < 1) splitk = 1;
-    if (splitk > 1 && out_mode != 2) return ISTVT_ERR_SHAPE;       // split-K only with atomic accumulation
+    if (splitk > 1 && out_mode < 2) return ISTVT_ERR_SHAPE;        // split-K needs atomics (2) or partial slabs (3)
     const int esz = dtype == DT_F32 ? 4 : 2;
     const int bk = dtype == DT_F32 ? 32 : 64;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.residual = residual;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epi = epi;
-    a.out_f32 = out_mode == 1; a.atomic_f32 = out_mode == 2; a.alpha = alpha;
+    a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
+    a.slab = out_mode == 3 ? (long)M * ldc : 0;
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + bk - 1) / bk) * bk;
     a.kper = kper;
     splitk = (K + kper - 1) / kper;
     a.a_vec = (((uintptr_t)A % 16) == 0 && (lda * esz) % 16 == 0) ? 1 : 0;
     a.b_vec = (((uintptr_t)B % 16) == 0 && (ldb * esz) % 16 == 0) ? 1 : 0;
+    // large bf16 problems: 256x256 DMA-staged kernel (NT for forward / dgrad-with-W^T, TN for wgrad)
+    const bool out16 = N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 &&
+                       (!residual || (ldr % 8 == 0 && ((uintptr_t)residual % 16) == 0)) &&
+                       (!C2 || ((uintptr_t)C2 % 16) == 0) && (!bias || ((uintptr_t)bias % 16) == 0);
+    if (dtype == DT_BF16 && a.a_vec && a.b_vec && out16 && M >= 192 && N >= 192 && a_kc == b_kc &&
+        (a_kc ? (K % 8 == 0) : (M % 8 == 0 && N % 8 == 0))) {
+        const int tiles = ((M + T256 - 1) / T256) * ((N + T256 - 1) / T256);
+        dim3 grid(tiles, 1, splitk), block(512);
+        if (a_kc) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, stream, a);
+        return istvt_check_launch();
+    }
     DISPATCH_DTYPE(dtype, return launch_gemm<T>(a, a_kc, b_kc, splitk, stream));
     return ISTVT_OK;
+}
+
+
+// out[i] += sum_z ws[z][i]   (second pass of split-K weight gradients written as partial slabs:
+// plain stores run ~4-5x the contended-atomic rate, and the sum order is fixed -> reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n,
+                                                            float* __restrict__ out) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        float4 acc = *reinterpret_cast<const float4*>(out + i);
+        for (int z = 0; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (long)z * n + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = acc;
+    }
+}
+
+extern "C" int istvt_splitk_reduce(const float* ws, int splits, long n, float* out, hipStream_t stream) {
+    if (splits < 1 || n <= 0 || n % 4 != 0) return ISTVT_ERR_SHAPE;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, splits, n, out);
+    return istvt_check_launch();
 }

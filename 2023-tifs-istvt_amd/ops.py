@@ -123,24 +123,59 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Op
     return y
 
 
-def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None) -> Tensor:
-    """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u)."""
+def weight_t_as(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """W^T ([K,N] contiguous) of a [N,K] parameter in the compute dtype, cached per parameter
+    version.  With it the input gradient dx = dy W is the same k-contiguous ("NT") GEMM as the
+    forward, i.e. it runs on the DMA-staged 256x256 kernel; transposing 88 M weights once per
+    optimizer step is noise next to transposing activations."""
+    key = (id(w), 't')
+    hit = _wcache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].dtype == dtype:
+        return hit[2]
+    out = weight_as(w, dtype).t().contiguous()
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)
+    return out
+
+
+def _transposed_operand(w: Tensor) -> Tensor:
+    """w^T of an already-cast GEMM operand (the per-version cached bf16 weight copy), cached for
+    as long as that operand tensor lives."""
+    key = (id(w), 'T')
+    hit = _wcache.get(key)
+    if hit is not None and hit[0]() is w:
+        return hit[2]
+    wt = w.t().contiguous()
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), 0, wt)
+    return wt
+
+
+def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Optional[Tensor] = None) -> Tensor:
+    """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u).
+    wt = w^T [K,N] (optional): use the k-contiguous kernel instead of the transposed-operand one."""
     M, N = dy.shape
     K = w.shape[1]
     dy = _c(dy)
     dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
-    if gelu_u is not None:
-        gemm_raw(dy, N, True, w, K, False, dx, K, M, K, N, C2=_c(gelu_u), epi=2)
+    epi = 2 if gelu_u is not None else 0
+    c2 = _c(gelu_u) if gelu_u is not None else None
+    if wt is None and dy.dtype == torch.bfloat16 and M >= 192 and K >= 192 and N % 8 == 0:
+        wt = _transposed_operand(w)
+    if wt is not None:
+        gemm_raw(dy, N, True, wt, N, True, dx, K, M, K, N, C2=c2, epi=epi)
     else:
-        gemm_raw(dy, N, True, w, K, False, dx, K, M, K, N)
+        gemm_raw(dy, N, True, w, K, False, dx, K, M, K, N, C2=c2, epi=epi)
     return dx
 
 
-def _pick_splitk(out_rows: int, out_cols: int, red: int) -> int:
-    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    s = max(1, 1024 // tiles)
-    s = min(s, max(1, red // 512))
-    return s
+def _pick_splitk(out_rows: int, out_cols: int, red: int, big_tiles: bool = False) -> int:
+    """split of the reduction dim for weight gradients so the grid fills the 256 CUs."""
+    if big_tiles:          # 256x256 kernel, one workgroup per CU
+        tiles = ((out_rows + 255) // 256) * ((out_cols + 255) // 256)
+        s = max(1, 256 // tiles)
+    else:
+        tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+        s = max(1, 1024 // tiles)
+    return min(s, max(1, red // 512))
 
 
 def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -150,7 +185,20 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     dy, x = _c(dy), _c(x)
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
-    gemm_raw(dy, N, False, x, K, False, out, K, N, K, M, out_mode=2, splitk=_pick_splitk(N, K, M))
+    big = dy.dtype == torch.bfloat16 and N >= 192 and K >= 192 and N % 8 == 0 and K % 8 == 0
+    splits = _pick_splitk(N, K, M, big)
+    if big:
+        # partial slabs + a reduce pass: every split of a tile finishes at the same moment, so
+        # atomics into the same 256x256 tile contend (measured 3-8x slower than this)
+        splits = min(splits, (M + 63) // 64)
+        kper = -(-(-(-M // splits)) // 64) * 64          # what the C side derives: ceil(ceil(M/s)/64)*64
+        splits = -(-M // kper)
+        ws = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+        gemm_raw(dy, N, False, x, K, False, ws, K, N, K, M, out_mode=3, splitk=splits)
+        _lib.check(_lib.lib().istvt_splitk_reduce(ws.data_ptr(), splits, N * K, out.data_ptr(), _stream()),
+                   'istvt_splitk_reduce')
+    else:
+        gemm_raw(dy, N, False, x, K, False, out, K, N, K, M, out_mode=2, splitk=splits)
     return out
 
 

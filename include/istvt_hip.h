@@ -41,10 +41,14 @@ typedef void* istvt_stream_t; /* hipStream_t */
  * bias: float[N] or NULL.  residual: T[M][ldr] or NULL (added after activation handling).
  * epi: 0 none; 1 GELU forward (exact erf, module.py:28): C = pre-activation, C2 = gelu;
  *      2 GELU backward: C = acc * gelu'(C2).
- * out_mode: 0 store T; 1 store float; 2 atomicAdd into float C (required when splitk > 1). */
+ * out_mode: 0 store T; 1 store float; 2 atomicAdd into float C; 3 split z stores its float partial
+ *           at C + z*M*ldc (caller sums them with istvt_splitk_reduce).  splitk > 1 needs 2 or 3. */
 int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
                int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
                float alpha, int dtype, istvt_stream_t stream);
+
+/* out[i] += sum_z ws[z*n + i]: second pass of a split-K weight gradient written as partial slabs */
+int istvt_splitk_reduce(const float* ws, int splits, long n, float* out, istvt_stream_t stream);
 
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
 int istvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

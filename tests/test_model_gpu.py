@@ -60,11 +60,19 @@ def test_g5_native_end_to_end_hip(golden_dir):
     named = dict(model.named_parameters())
     got = sorted(k for k, p in named.items() if p.grad is not None)
     assert got == sorted(live)                        # the 19.7 M dead Xception params get no gradient
-    worst = max((relerr(named[k].grad.norm(), g['gnorm.' + k]), k) for k in live)
-    assert worst[0] < 2e-2, worst
+    # relative 2e-2 plus an absolute floor of 2e-6 x the largest gradient norm: with these recipe
+    # weights some temporal softmaxes are saturated and their to_qk gradients sit at 1e-7..1e-5,
+    # seven orders below the rest, i.e. at the fp32 noise floor of p*(dp - delta) -- the
+    # reference's own fp32 value for layers.6.0.fn.to_qk.weight is 7 % off its fp64 value.
+    gmax = max(float(g['gnorm.' + k]) for k in live)
+    bad = [(k, float(named[k].grad.norm()), float(g['gnorm.' + k])) for k in live
+           if abs(float(named[k].grad.norm()) - float(g['gnorm.' + k])) > 2e-2 * float(g['gnorm.' + k]) + 2e-6 * gmax]
+    assert not bad, bad[:8]
     for k in g.files:
-        if k.startswith('grad.'):
-            assert relerr(named[k[5:]].grad.reshape(-1)[:64], g[k]) < 2e-2, k
+        if k.startswith('grad.'):          # 64-entry slices; same relative + noise-floor criterion
+            got_s = named[k[5:]].grad.reshape(-1)[:64].double().cpu()
+            ref_s = torch.from_numpy(g[k]).double()
+            assert float((got_s - ref_s).norm()) <= 2e-2 * float(ref_s.norm()) + 1e-7 * gmax, k
     opt.step()
     for k in g.files:
         if k.startswith('after_sgd.'):

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GEMM kernels at the model's shapes (run on the GPU box)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import istvt_pkg  # noqa: E402
+
+istvt_pkg.load()
+from istvt_amd import ops  # noqa: E402
+
+M = int(os.environ.get('GB_M', 56736))
+reps = int(os.environ.get('GB_REPS', 10))
+which = os.environ.get('GB_WHICH', 'all')
+dt = torch.bfloat16
+
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def rnd(*s):
+    return (torch.randn(*s, device='cuda') * 0.5).to(dt)
+
+
+shapes = [(728, 2912), (2912, 728), (728, 1536), (512, 728), (728, 1024), (728, 512)]
+for K, N in shapes:
+    x, w = rnd(M, K), rnd(N, K)
+    b = torch.randn(N, device='cuda')
+    res = rnd(M, N)
+    fl = 2.0 * M * N * K
+    if which in ('all', 'fwd'):
+        t = timeit(lambda: ops.linear_fwd(x, w))
+        print('fwd   plain    M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
+        t = timeit(lambda: ops.linear_fwd(x, w, b, res))
+        print('fwd   bias+res M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
+    if which in ('all', 'gelu') and N == 2912:
+        t = timeit(lambda: ops.linear_fwd(x, w, b, gelu=True))
+        print('fwd   gelu     M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
+    if which in ('all', 'wgrad'):
+        dy = rnd(M, N)
+        out = torch.zeros(N, K, device='cuda')
+        t = timeit(lambda: ops.linear_wgrad(dy, x, out))
+        print('wgrad          M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
