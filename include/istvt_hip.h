@@ -88,6 +88,56 @@ int istvt_tokens_bwd(const void* dx, void* dfeats, float* dspace, float* dtempor
 int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int adjoint, int dtype,
                      istvt_stream_t stream);
 
+/* ==== Xception entry flow (network/xception.py:193-206), NHWC activations [frames][H][W][C] ====
+ * A finalized BatchNorm travels as ONE device pointer `bnp` to a float[4][C] pack
+ * {mean, rstd, scale = gamma*rstd, beta}; consumers apply z = (u - mean)*scale + beta. */
+
+/* train-mode nn.BatchNorm2d (xception.py:58,69,75,119,123): sum/sumsq are double[C] accumulators */
+int istvt_bn_stats(const void* x, double* sum, double* sumsq, long M, int C, int dtype, istvt_stream_t stream);
+/* use_batch=1: batch statistics (+ running-stat update, momentum/unbiased var as torch);
+ * use_batch=0: running statistics (eval mode).  Writes the pack. */
+int istvt_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* bnp, int C,
+                      int use_batch, int update_running, istvt_stream_t stream);
+int istvt_bn_apply(const void* x, const float* bnp, void* y, long M, int C, int relu, int dtype,
+                   istvt_stream_t stream);
+/* s1 += sum dz, s2 += sum dz*xhat (double[C]);  du = gamma*rstd*(dz - s1/M - xhat*s2/M), dgamma += s2, dbeta += s1 */
+int istvt_bn_bwd_stats(const void* dz, const void* u, const float* bnp, double* s1, double* s2, long M, int C,
+                       int dtype, istvt_stream_t stream);
+int istvt_bn_bwd_apply(const void* dz, const void* u, const float* bnp, const float* gamma, const double* s1,
+                       const double* s2, void* du, float* dgamma, float* dbeta, long M, int C, int dtype,
+                       istvt_stream_t stream);
+
+/* conv1 (3->32, 3x3, s2, p0; xception.py:118): NCHW float clip -> col[M][32] ((dy,dx,ci) + 5 zero cols); adjoint */
+int istvt_im2col_conv1(const float* x, void* col, int frames, int S, int dtype, istvt_stream_t stream);
+int istvt_col2im_conv1(const void* dcol, float* dx, int frames, int S, int dtype, istvt_stream_t stream);
+/* conv2 (32->64, 3x3, p0; xception.py:122): NHWC source with optional BN pack (+ReLU) on load -> col[M][9*C];
+ * adjoint gathers dcol and masks by relu'(bn(u)) */
+int istvt_im2col3x3(const void* src, const float* bnp, int relu, void* col, int frames, int H, int W, int C,
+                    int dtype, istvt_stream_t stream);
+int istvt_col2im3x3(const void* dcol, const void* u, const float* bnp, void* dz, int frames, int H, int W, int C,
+                    int dtype, istvt_stream_t stream);
+
+/* depthwise 3x3 s1 p1 (SeparableConv2d.conv1, xception.py:43), LDS-tiled.  w: float[C][9].
+ * forward: in_bn (+in_relu) = the preceding BatchNorm+ReLU applied on load (xception.py:67,73).
+ * input gradient (flip=1): epilogue = ReLU mask of msrc (optionally through m_bn) before (mask_pre) /
+ * after (mask_post) adding the stride-2 skip-path gradient addsrc[f][y/2][x/2], plus fused
+ * BatchNorm-backward sums st_s1/st_s2 (double[C]) of the result w.r.t. m_bn. */
+int istvt_dwconv3x3(const void* in, const float* w, void* out, int frames, int H, int W, int C, const float* in_bn,
+                    int in_relu, int flip, const void* msrc, const float* m_bn, int mask_pre, int mask_post,
+                    const void* addsrc, int Ha, int Wa, double* st_s1, double* st_s2, int dtype,
+                    istvt_stream_t stream);
+int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw, int frames,
+                          int H, int W, int C, int dtype, istvt_stream_t stream);
+
+/* Block tail (xception.py:88,91-100): out = maxpool3x3s2p1(bn_x(x)) + bn_s(skip); argmax: uint8 per output element */
+int istvt_pool_add_fwd(const void* x, const float* bnx, const void* skip, const float* bns, void* out,
+                       unsigned char* argmax, int frames, int H, int W, int C, int dtype, istvt_stream_t stream);
+int istvt_pool_bwd(const void* dout, const unsigned char* argmax, void* dz, int frames, int H, int W, int C,
+                   int dtype, istvt_stream_t stream);
+/* input of the stride-2 1x1 skip conv (xception.py:57): out[f][y][x] = in[f][2y][2x] */
+int istvt_subsample2(const void* in, void* out, int frames, int H, int W, int C, int dtype, istvt_stream_t stream);
+
 /* ---- helpers -------------------------------------------------------------------------------- */
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, istvt_stream_t stream);

@@ -230,7 +230,21 @@ def g6_fullwidth():
     save('G6_fullwidth', **out)
 
 
-ALL = {'G1': g1_stem, 'G2': g2_modules, 'G3': g3_layer, 'G4': g4_dsttr, 'G5': g5_end_to_end, 'G6': g6_fullwidth}
+def g0_state_dict():
+    """names, shapes and parameter count of the reference XceptionVidTr().state_dict()
+    (checkpoint interchange, train_CNN.py:183,999-1011)."""
+    import json
+    model = ref_vivit.XceptionVidTr()
+    sd = model.state_dict()
+    out = {'entries': [[k, list(v.shape)] for k, v in sd.items()],
+           'num_parameters': sum(p.numel() for p in model.parameters())}
+    path = os.path.join(HERE, 'G0_state_dict.json')
+    with open(path, 'w') as f:
+        json.dump(out, f)
+    print('wrote', path, len(out['entries']), 'entries')
+
+
+ALL = {'G0': g0_state_dict, 'G1': g1_stem, 'G2': g2_modules, 'G3': g3_layer, 'G4': g4_dsttr, 'G5': g5_end_to_end, 'G6': g6_fullwidth}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -1,0 +1,170 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/istvt_hip.h
+declares, the nn.Module mirror keeps the reference's constructor surface and state-dict names,
+the product path refuses to run without a GPU (no fallback), and the data-parallel gradient
+bucket is correct across 2 gloo ranks."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import istvt_pkg
+    return istvt_pkg.load()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    from istvt_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.lib()                                  # resolves all SIGNATURES or raises
+    header = open(os.path.join(ROOT, 'include', 'istvt_hip.h')).read()
+    declared = set(re.findall(r'\bint\s+(istvt_\w+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libistvt_hip.so lacks %s declared in include/istvt_hip.h' % name
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path, monkeypatch):
+    from istvt_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.IstvtLibraryError):
+        _lib.lib()
+
+
+def test_no_cpu_fallback(pkg):
+    from istvt_amd.network.vivit import module as M
+    from istvt_amd.network.vivit.vivit import XceptionVidTr
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        M.FeedForward(64, 128)(torch.zeros(1, 4, 64))
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        XceptionVidTr(num_frames=2, grid=6, depth=1)(torch.zeros(1, 2, 3, 96, 96))
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, '2023-tifs-istvt_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_state_dict_matches_reference(pkg, golden_dir):
+    """names + shapes of XceptionVidTr().state_dict() equal the reference's (captured in G0)."""
+    from istvt_amd.network.vivit.vivit import XceptionVidTr
+    ref = json.load(open(os.path.join(golden_dir, 'G0_state_dict.json')))
+    sd = XceptionVidTr().state_dict()
+    assert list(sd.keys()) == [k for k, _ in ref['entries']]
+    for k, shape in ref['entries']:
+        assert list(sd[k].shape) == shape, k
+    assert sum(p.numel() for p in XceptionVidTr().parameters()) == ref['num_parameters'] == 109172051
+
+
+def test_constructor_surface(pkg):
+    from istvt_amd.network.vivit import module as M, vivit as V
+    from istvt_amd.network import xception as X
+    from istvt_amd.network.models import model_selection, TransferModel
+    V.DSTTr(19, 1, 1, 6, 728, 1, 8, 'cls', 728, 64, 0., 0., 4)            # positional, as vivit.py:104-105
+    V.STTransformer(64, 1, 2, 32, 128, 0.)
+    M.TemporalResidualAttention(64, 2, 32, 0.)
+    M.SpatialOnlyAttention(64, 2, 32, 0.)
+    M.FeedForward(64, 128, 0.)
+    M.PreNorm(64, M.FeedForward(64, 128))
+    X.SeparableConv2d(64, 128, 3, 1, 1, 1, False)
+    X.Block(64, 128, 2, 2, False, True)
+    assert X.Block(128, 256, 2, 2, True, True).rep[0].inplace is False          # skip sees the un-rectified input
+    assert [n for n, _ in X.Block(64, 128, 2, 2, start_with_relu=False).rep.named_children()] == ['0', '1', '2', '3', '4', '5']
+    m = model_selection('xception', 2, dropout=0.5, batch_size=1)
+    assert isinstance(m, TransferModel) and hasattr(m, 'low_level_features')
+    assert m.model.last_linear[1].out_features == 2
+    assert type(model_selection('resnet_3d', 1, dropout=0.5, batch_size=4)).__name__ == 'XceptionVidTr'
+    with pytest.raises(Exception, match='Choose valid model'):
+        model_selection('resnet50', 1)
+
+
+def test_live_parameters_and_bucket(pkg):
+    from istvt_amd import parallel
+    from istvt_amd.network.vivit.vivit import XceptionVidTr
+    model = XceptionVidTr(num_frames=8, grid=14)
+    live = parallel.live_named_parameters(model)
+    n = sum(p.numel() for _, p in live)
+    assert n == 89033873                     # 1,106,760 stem + 87,927,113 transformer
+    small = XceptionVidTr(num_frames=2, grid=6, depth=1)
+    ps = [p for _, p in parallel.live_named_parameters(small)]
+    b = parallel.GradBucket(ps)
+    assert all(p.grad.data_ptr() >= b.flat.data_ptr() for p in ps)
+    ps[0].grad.add_(1.0)
+    assert float(b.flat.sum()) == ps[0].numel()
+    b.zero()
+    assert float(b.flat.abs().sum()) == 0.0
+
+
+_DP_WORKER = r'''
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import istvt_pkg; istvt_pkg.load()
+from istvt_amd import parallel
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+torch.manual_seed(1234 + rank)                      # deliberately different init per rank
+lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 1))
+parallel.broadcast_parameters(lin)                  # -> rank 0's weights everywhere
+params = list(lin.parameters())
+bucket = parallel.GradBucket(params)
+g = torch.Generator().manual_seed(7)
+x = torch.randn(8, 6, generator=g); y = (torch.rand(8, generator=g) > .5).float()
+xs, ys = parallel.shard_batch(x, rank, world), parallel.shard_batch(y, rank, world)
+bucket.zero()
+loss = torch.nn.functional.binary_cross_entropy_with_logits(lin(xs).view(-1), ys)
+loss.backward()
+bucket.all_reduce(chunks=2)
+# single-process reference on the concatenated batch with rank 0's weights
+ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 1))
+ref.load_state_dict(lin.state_dict())
+torch.nn.functional.binary_cross_entropy_with_logits(ref(x).view(-1), y).backward()
+err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(lin.parameters(), ref.parameters()))
+w0 = [float(p.detach().sum()) for p in lin.parameters()]
+out = torch.tensor(w0); gathered = [torch.zeros_like(out) for _ in range(world)]
+dist.all_gather(gathered, out)
+same = all(torch.equal(gathered[0], t) for t in gathered)
+if rank == 0:
+    print(json.dumps({'err': err, 'same_weights': same}))
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_two_ranks_gloo(tmp_path):
+    """W-rank averaged gradients == 1-rank gradients on the concatenated batch."""
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['same_weights']
+    assert res['err'] < 1e-6
+
+
+def test_bench_cli_contract():
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for flag in ('--gpus', '--steps', '--warmup'):
+        assert flag in src
+    for key in ('"metric"', 'roofline', 'cpu_baseline', 'ms_per_step', 'n_gpus', 'vs_baseline'):
+        assert key.strip('"') in src
