@@ -25,6 +25,8 @@ SIGNATURES = {
     'istvt_tokens_fwd': [P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_tokens_bwd': [P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],
+    'istvt_stats_replicas': [],
+    'istvt_stats_reduce': [P, I, P],
     'istvt_bn_stats': [P, P, P, L, I, I, P],
     'istvt_bn_finalize': [P, P, ctypes.c_double, P, P, P, P, F, F, P, I, I, I, P],
     'istvt_bn_apply': [P, P, P, L, I, I, I, P],

@@ -31,6 +31,29 @@ __device__ __forceinline__ void bn_affine8(float (&v)[8], const float* bnp, int 
 // ============================================================================================
 // column reductions over a [M][C] matrix, C % 8 == 0
 // ============================================================================================
+// Per-channel statistics are accumulated with fp64 atomics.  Thousands of workgroups adding to the
+// SAME C addresses serialise at the memory side (measured: every bn_stats launch took ~400 us
+// whatever its size), so accumulators are replicated: a statistics buffer is double[R][2][C],
+// workgroup b adds into replica b % R, and istvt_stats_reduce folds replicas 1..R-1 into replica 0,
+// which is what the consumers (finalize, backward-apply) read.  The C ABI passes pointers to
+// replica 0's two rows.
+constexpr int STAT_REPLICAS = 32;
+
+__global__ void stats_reduce_kernel(double* acc, int n2c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2c) return;
+    double s = acc[i];
+    for (int r = 1; r < STAT_REPLICAS; ++r) s += acc[(long)r * n2c + i];
+    acc[i] = s;
+}
+
+extern "C" int istvt_stats_replicas() { return STAT_REPLICAS; }
+
+extern "C" int istvt_stats_reduce(double* acc, int C, hipStream_t stream) {
+    if (C <= 0) return ISTVT_ERR_SHAPE;
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, acc, 2 * C);
+    return istvt_check_launch();
+}
 template <int NACC, typename F>
 __device__ __forceinline__ void colreduce_block(F f, double* const (&out)[NACC], long M, int C, int rows_per_block) {
     __shared__ float red[NACC][256][8];
@@ -47,8 +70,10 @@ __device__ __forceinline__ void colreduce_block(F f, double* const (&out)[NACC],
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = min(M, r0 + (long)rows_per_block);
     const int c0 = (vc0 + tcol) * 8;
-    if (trow < RS)
-        for (long m = r0 + trow; m < r1; m += RS) f(m, c0, acc);
+    if (trow < RS) {
+#pragma unroll 4
+        for (long m = r0 + trow; m < r1; m += RS) f(m, c0, acc);      // 4 rows of loads in flight per thread
+    }
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -61,7 +86,7 @@ __device__ __forceinline__ void colreduce_block(F f, double* const (&out)[NACC],
             for (int i = 0; i < 8; ++i) {
                 float s = 0.f;
                 for (int t = 0; t < RS; ++t) s += red[a][threadIdx.x + t * vcg][i];
-                atomicAdd(out[a] + c0 + i, (double)s);
+                atomicAdd(out[a] + (long)(blockIdx.y % STAT_REPLICAS) * 2 * C + c0 + i, (double)s);
             }
     }
 }
@@ -457,14 +482,18 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 
     const int ch = tid & 3;                       // 8-channel chunk of this thread (same for both items)
     const int c = c0 + ch * 8;
+    // weights are passed tap-major ([9][C]): a thread's 8 channels of one tap are one 32-byte load
+    // (the PyTorch [C][9] order costs 72 scalar loads per thread and dominated the kernel)
     float wv[9][8];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap) {
+        const int src_tap = p.flip ? 8 - tap : tap;
+        if (c < p.C) load8(p.w + (long)src_tap * p.C + c, wv[tap]);
+        else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int src_tap = p.flip ? 8 - tap : tap;
-            wv[tap][j] = (c + j < p.C) ? p.w[(long)(c + j) * 9 + src_tap] : 0.f;
+            for (int j = 0; j < 8; ++j) wv[tap][j] = 0.f;
         }
+    }
     __syncthreads();
 
     float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -540,8 +569,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         }
         __syncthreads();
         if (tid < DW_CC && c0 + tid < p.C) {
-            atomicAdd(p.st_s1 + c0 + tid, (double)(sred[0][0][tid] + sred[0][1][tid] + sred[0][2][tid] + sred[0][3][tid]));
-            atomicAdd(p.st_s2 + c0 + tid, (double)(sred[1][0][tid] + sred[1][1][tid] + sred[1][2][tid] + sred[1][3][tid]));
+            const long rep = (long)(blockIdx.x % STAT_REPLICAS) * 2 * p.C;
+            atomicAdd(p.st_s1 + rep + c0 + tid, (double)(sred[0][0][tid] + sred[0][1][tid] + sred[0][2][tid] + sred[0][3][tid]));
+            atomicAdd(p.st_s2 + rep + c0 + tid, (double)(sred[1][0][tid] + sred[1][1][tid] + sred[1][2][tid] + sred[1][3][tid]));
         }
     }
 }

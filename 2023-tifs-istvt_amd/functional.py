@@ -1,6 +1,12 @@
 """torch.autograd.Function glue: each Function is a thin autograd wrapper whose forward and
 backward are sequences of HIP launches (ops.py).  No arithmetic is done with torch ops here
-except zero-initialising gradient buffers."""
+except zero-initialising gradient buffers.
+
+Fused gradient accumulation: when a parameter was registered with
+``parallel.GradBucket(..., fuse_accumulate=True)`` its ``.grad`` (a view into the flat fp32
+bucket) is handed to the weight-gradient kernels as their accumulate target and the Function
+returns ``None`` for it, which removes one zero-fill and one add pass per parameter per step.
+"""
 from __future__ import annotations
 
 import torch
@@ -12,8 +18,14 @@ from . import ops
 Tensor = torch.Tensor
 
 
-def _zeros_like_f32(p: Tensor) -> Tensor:
-    return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+def _target(p):
+    """(buffer to accumulate this parameter's gradient into, value to return to autograd)"""
+    if p is None:
+        return None, None
+    if getattr(p, '_istvt_fused_grad', False) and p.grad is not None:
+        return p.grad, None
+    z = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+    return z, z
 
 
 class LayerNormFn(Function):
@@ -22,16 +34,17 @@ class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
-        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, mean, rstd, gamma = ctx.saved_tensors
-        dg, db = _zeros_like_f32(gamma), _zeros_like_f32(gamma)
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dg, rg = _target(gamma)
+        db, rb = _target(beta)
         dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db)
-        return dx, dg, db, None
+        return dx, rg, rb, None
 
 
 class LayerNormDiffFn(Function):
@@ -40,18 +53,19 @@ class LayerNormDiffFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, B, F, P):
         y, diff, mean, rstd = ops.layernorm_fwd_diff(x, gamma, beta, eps, B, F, P)
-        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.geom = (F, P)
         return y, diff
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, ddiff):
-        x, mean, rstd, gamma = ctx.saved_tensors
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
         F, P = ctx.geom
-        dg, db = _zeros_like_f32(gamma), _zeros_like_f32(gamma)
+        dg, rg = _target(gamma)
+        db, rb = _target(beta)
         dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, F=F, P=P)
-        return dx, dg, db, None, None, None, None
+        return dx, rg, rb, None, None, None, None
 
 
 class FrameDiffFn(Function):
@@ -68,6 +82,20 @@ class FrameDiffFn(Function):
         return ops.frame_diff(g, *ctx.geom, adjoint=True), None, None, None
 
 
+def _wgrad(dy, x, weight):
+    buf, ret = _target(weight)
+    ops.linear_wgrad(dy, x, out=buf.view(weight.shape[0], -1))
+    return ret
+
+
+def _bgrad(dy, bias):
+    if bias is None:
+        return None
+    buf, ret = _target(bias)
+    ops.colsum(dy, out=buf)
+    return ret
+
+
 class LinearFn(Function):
     """y = x W^T (+ b) (+ residual) on [M, K] inputs (nn.Linear, module.py:74,77,182,183,186)."""
 
@@ -75,20 +103,19 @@ class LinearFn(Function):
     def forward(ctx, x, weight, bias, residual):
         w = ops.weight_as(weight, x.dtype)
         y = ops.linear_fwd(x, w, bias, residual)
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, bias)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         dy = dy.contiguous()
         w = ops.weight_as(weight, dy.dtype)
         dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = ops.linear_wgrad(dy, x).view(weight.shape) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw = _wgrad(dy, x, weight) if ctx.needs_input_grad[1] else None
+        db = _bgrad(dy, bias) if (bias is not None and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres
 
@@ -100,21 +127,21 @@ class FeedForwardFn(Function):
     def forward(ctx, x, w1, b1, w2, b2, residual):
         u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype), b1, gelu=True)
         y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype), b2, residual)
-        ctx.save_for_backward(x, u, g, w1, w2)
+        ctx.save_for_backward(x, u, g, w1, b1, w2, b2)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, u, g, w1, w2 = ctx.saved_tensors
+        x, u, g, w1, b1, w2, b2 = ctx.saved_tensors
         dy = dy.contiguous()
         du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype), gelu_u=u)       # (dy W2) * gelu'(u)
-        dw2 = ops.linear_wgrad(dy, g)
-        db2 = ops.colsum(dy)
+        dw2 = _wgrad(dy, g, w2)
+        db2 = _bgrad(dy, b2)
         dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype)) if ctx.needs_input_grad[0] else None
-        dw1 = ops.linear_wgrad(du, x)
-        db1 = ops.colsum(du)
+        dw1 = _wgrad(du, x, w1)
+        db1 = _bgrad(du, b1)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
 
@@ -168,9 +195,9 @@ class TokensFn(Function):
     def backward(ctx, dx):
         space, temporal, pos = ctx.saved_tensors
         B, T, hw, D = ctx.geom
-        ds, dt, dp = _zeros_like_f32(space), _zeros_like_f32(temporal), _zeros_like_f32(pos)
+        (ds, rs), (dt, rt), (dp, rp) = _target(space), _target(temporal), _target(pos)
         dfeats = ops.tokens_bwd(dx, B, T, hw, D, ds, dt, dp, ctx.needs_input_grad[0])
-        return dfeats, ds, dt, dp
+        return dfeats, rs, rt, rp
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

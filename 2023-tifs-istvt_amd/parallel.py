@@ -36,8 +36,12 @@ def live_named_parameters(model: torch.nn.Module) -> List[Tuple[str, torch.nn.Pa
 class GradBucket:
     """Flat fp32 gradient buffer; every live parameter's ``.grad`` is a view into it."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], fuse_accumulate: bool = False):
+        """fuse_accumulate: let the HIP weight-gradient kernels add straight into the bucket
+        (functional._target) instead of returning fresh tensors for autograd to add."""
         self.params = list(params)
+        for p in self.params:
+            p._istvt_fused_grad = bool(fuse_accumulate)
         if not self.params:
             raise ValueError('GradBucket needs at least one parameter')
         dev = self.params[0].device

@@ -49,15 +49,33 @@ class BNState:
         return self.pack.data_ptr()
 
 
+_REPLICAS = None
+
+
+def new_stats(C: int, device) -> Tensor:
+    """zeroed per-channel statistics accumulator double[R][2][C]; kernels add into replica
+    (workgroup % R) to spread same-address atomics, reduce_stats() folds them into replica 0."""
+    global _REPLICAS
+    if _REPLICAS is None:
+        fn = _lib.lib().istvt_stats_replicas
+        _REPLICAS = int(fn())
+    return torch.zeros((_REPLICAS, 2, C), dtype=torch.float64, device=device)
+
+
+def reduce_stats(acc: Tensor, C: int):
+    _lib.check(_lib.lib().istvt_stats_reduce(acc.data_ptr(), C, _stream()), 'istvt_stats_reduce')
+
+
 def bn_forward_stats(u: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor,
                      training: bool) -> BNState:
     st = BNState(C, u.device)
     L = _lib.lib()
     if training:
-        acc = torch.zeros((2, C), dtype=torch.float64, device=u.device)
-        _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), M, C, dtype_code(u), _stream()),
+        acc = new_stats(C, u.device)
+        _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0, 0].data_ptr(), acc[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
                    'istvt_bn_stats')
-        s0, s1 = acc[0].data_ptr(), acc[1].data_ptr()
+        reduce_stats(acc, C)
+        s0, s1 = acc[0, 0].data_ptr(), acc[0, 1].data_ptr()
     else:
         s0 = s1 = None
     _lib.check(L.istvt_bn_finalize(s0, s1, float(M), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
@@ -74,19 +92,21 @@ def bn_apply(u: Tensor, st: BNState, M: int, C: int, relu: bool) -> Tensor:
 
 
 def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: int, stats: Optional[Tensor] = None):
-    """-> (du, dgamma, dbeta).  `stats` = [2][C] fp64 sums already accumulated by a fused producer."""
+    """-> (du, dgamma, dbeta).  `stats` = new_stats() buffer already accumulated (not yet reduced) by a
+    fused producer (the depthwise input-gradient kernel)."""
     L = _lib.lib()
     if stats is None:
-        stats = torch.zeros((2, C), dtype=torch.float64, device=u.device)
+        stats = new_stats(C, u.device)
         _lib.check(L.istvt_bn_bwd_stats(dz.data_ptr(), u.data_ptr(), st.ptr(),
-                                        stats[0].data_ptr(), stats[1].data_ptr(), M, C, dtype_code(u), _stream()),
+                                        stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
                    'istvt_bn_bwd_stats')
+    reduce_stats(stats, C)
     du = torch.empty_like(u)
     dg = torch.zeros((C,), dtype=torch.float32, device=u.device)
     db = torch.zeros((C,), dtype=torch.float32, device=u.device)
     _lib.check(L.istvt_bn_bwd_apply(dz.data_ptr(), u.data_ptr(), st.ptr(), gamma.data_ptr(),
-                                    stats[0].data_ptr(), stats[1].data_ptr(), du.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                    M, C, dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
+                                    stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), du.data_ptr(), dg.data_ptr(),
+                                    db.data_ptr(), M, C, dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
     return du, dg, db
 
 
@@ -102,7 +122,7 @@ def dwconv(x: Tensor, w9: Tensor, Fr: int, H: int, W: int, C: int, *, in_bn: Opt
         in_bn.ptr() if in_bn else None, int(in_relu), int(flip),
         _ptr(msrc), m_bn.ptr() if m_bn else None, int(mask_pre), int(mask_post),
         _ptr(addsrc), Ha, Wa,
-        stats[0].data_ptr() if stats is not None else None, stats[1].data_ptr() if stats is not None else None,
+        stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None,
         dtype_code(x), _stream()), 'istvt_dwconv3x3')
     return out
 
@@ -207,9 +227,9 @@ class StemFn(Function):
             M = Fr * H * H
             Hs = (H - 1) // 2 + 1
             Ms = Fr * Hs * Hs
-            wdwA = P['%s.rep.%d.conv1.weight' % (name, i0)].detach().reshape(cin_, 9)
+            wdwA = P['%s.rep.%d.conv1.weight' % (name, i0)].detach().reshape(cin_, 9).t().contiguous()   # tap-major [9][C]
             wpwA = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0)], dtype)
-            wdwB = P['%s.rep.%d.conv1.weight' % (name, i0 + 3)].detach().reshape(cout, 9)
+            wdwB = P['%s.rep.%d.conv1.weight' % (name, i0 + 3)].detach().reshape(cout, 9).t().contiguous()
             wpwB = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0 + 3)], dtype)
             wsk = ops.weight_as(P[name + '.skip.weight'], dtype)
             d1 = dwconv(X, wdwA, Fr, H, H, cin_, in_relu=pre_relu)
@@ -272,7 +292,7 @@ class StemFn(Function):
             dd2 = ops.linear_dgrad(duB, blk['wpwB'])
             del duB
             grads[sB + '.conv1.weight'] = dwconv_wgrad(blk['uA'], dd2, Fr, H, H, cout, blk['bnA'], True)
-            statsA = torch.zeros((2, cout), dtype=torch.float64, device=dev)
+            statsA = new_stats(cout, dev)
             dzA = dwconv(dd2, blk['wdwB'], Fr, H, H, cout, flip=True, msrc=blk['uA'], m_bn=blk['bnA'], mask_pre=True,
                          stats=statsA)
             del dd2
@@ -290,7 +310,7 @@ class StemFn(Function):
                 dOut = dwconv(dd1, blk['wdwA'], Fr, H, H, cin, flip=True, msrc=blk['X'], mask_pre=True, addsrc=dxs)
             else:
                 # block1: its input is relu(bn2(u2)); fold that ReLU mask and bn2's backward statistics in
-                stats2 = torch.zeros((2, cin), dtype=torch.float64, device=dev)
+                stats2 = new_stats(cin, dev)
                 dOut = dwconv(dd1, blk['wdwA'], Fr, H, H, cin, flip=True, msrc=sv['u2'], m_bn=sv['bn2'], mask_post=True,
                               addsrc=dxs, stats=stats2)
             del dd1

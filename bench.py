@@ -97,7 +97,7 @@ def main():
     model = XceptionVidTr(num_frames=a.frames, grid=grid, depth=a.depth, compute_dtype=dtype).to(dev).train()
     parallel.broadcast_parameters(model)
     live = [p for _, p in parallel.live_named_parameters(model)]
-    bucket = parallel.GradBucket(live)
+    bucket = parallel.GradBucket(live, fuse_accumulate=True)
     opt = torch.optim.SGD(live, lr=1e-3, momentum=0.9, weight_decay=0)     # train_CNN.py:200
     crit = torch.nn.BCEWithLogitsLoss()                                      # train_CNN.py:148
 

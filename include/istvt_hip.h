@@ -92,7 +92,14 @@ int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int a
  * A finalized BatchNorm travels as ONE device pointer `bnp` to a float[4][C] pack
  * {mean, rstd, scale = gamma*rstd, beta}; consumers apply z = (u - mean)*scale + beta. */
 
-/* train-mode nn.BatchNorm2d (xception.py:58,69,75,119,123): sum/sumsq are double[C] accumulators */
+/* Per-channel statistics accumulators are double[R][2][C] with R = istvt_stats_replicas(): producers
+ * (bn_stats, bn_bwd_stats, the fused sums of dwconv3x3) take pointers to replica 0's two rows and add
+ * into replica (workgroup % R) to spread same-address atomics; istvt_stats_reduce folds replicas
+ * 1..R-1 into replica 0, which finalize / bwd_apply then read. */
+int istvt_stats_replicas(void);
+int istvt_stats_reduce(double* acc, int C, istvt_stream_t stream);
+
+/* train-mode nn.BatchNorm2d (xception.py:58,69,75,119,123): sum/sumsq = rows 0/1 of replica 0 */
 int istvt_bn_stats(const void* x, double* sum, double* sumsq, long M, int C, int dtype, istvt_stream_t stream);
 /* use_batch=1: batch statistics (+ running-stat update, momentum/unbiased var as torch);
  * use_batch=0: running statistics (eval mode).  Writes the pack. */
@@ -118,7 +125,8 @@ int istvt_im2col3x3(const void* src, const float* bnp, int relu, void* col, int 
 int istvt_col2im3x3(const void* dcol, const void* u, const float* bnp, void* dz, int frames, int H, int W, int C,
                     int dtype, istvt_stream_t stream);
 
-/* depthwise 3x3 s1 p1 (SeparableConv2d.conv1, xception.py:43), LDS-tiled.  w: float[C][9].
+/* depthwise 3x3 s1 p1 (SeparableConv2d.conv1, xception.py:43), LDS-tiled.  w: float[9][C] (tap-major);
+ * the weight gradient dw is float[C][9] (PyTorch order).
  * forward: in_bn (+in_relu) = the preceding BatchNorm+ReLU applied on load (xception.py:67,73).
  * input gradient (flip=1): epilogue = ReLU mask of msrc (optionally through m_bn) before (mask_pre) /
  * after (mask_post) adding the stride-2 skip-path gradient addsrc[f][y/2][x/2], plus fused

@@ -239,7 +239,7 @@ def dwconv_check(dtype, Fr=3, H=21, W=37, C=40):
     bn = S.BNState(C, DEV)
     bn.scale.copy_(sc); bn.beta.copy_(sh); bn.mean.zero_(); bn.rstd.fill_(1.0)
     xn = _nhwc(x)
-    y = S.dwconv(xn, w.reshape(C, 9).contiguous(), Fr, H, W, C, in_bn=bn, in_relu=True)
+    y = S.dwconv(xn, w.reshape(C, 9).t().contiguous(), Fr, H, W, C, in_bn=bn, in_relu=True)
     xd = x.double().requires_grad_(True)
     wd = w.double().requires_grad_(True)
     a = torch.relu(xd * sc.double().view(1, C, 1, 1) + sh.double().view(1, C, 1, 1))
@@ -250,7 +250,7 @@ def dwconv_check(dtype, Fr=3, H=21, W=37, C=40):
     ref.backward(dout.double())
     e = relerr(y, _nhwc(ref))
     # input gradient w.r.t. a (flipped taps), masked by relu'(affine(x))
-    dz = S.dwconv(_nhwc(dout), w.reshape(C, 9).contiguous(), Fr, H, W, C, flip=True, msrc=xn, m_bn=bn, mask_pre=True)
+    dz = S.dwconv(_nhwc(dout), w.reshape(C, 9).t().contiguous(), Fr, H, W, C, flip=True, msrc=xn, m_bn=bn, mask_pre=True)
     ref_dz = xd.grad / sc.double().view(1, C, 1, 1)           # dL/dz with z = affine(x) pre-ReLU
     e = max(e, relerr(dz, _nhwc(ref_dz)))
     dw = S.dwconv_wgrad(xn, _nhwc(dout), Fr, H, W, C, bn, True)
@@ -402,8 +402,8 @@ def dwconv_epilogue_check(dtype, case, Fr=2, H=12, W=12, C=728):
     res = a.grad.clone()
     z = (u.float() - bn.mean.view(1, C, 1, 1)) * bn.scale.view(1, C, 1, 1) + bn.beta.view(1, C, 1, 1)
     v = lambda t: t.view(1, C, 1, 1)  # noqa: E731
-    stats = torch.zeros((2, C), dtype=torch.float64, device=DEV)
-    w9 = w.reshape(C, 9).contiguous()
+    stats = S.new_stats(C, DEV)
+    w9 =w.reshape(C, 9).t().contiguous()          # tap-major [9][C]
     if case == 'a':
         res = res * (z > 0)
         out = S.dwconv(_nhwc(dd), w9, Fr, H, W, C, flip=True, msrc=_nhwc(u), m_bn=bn, mask_pre=True, stats=stats)
@@ -418,9 +418,10 @@ def dwconv_epilogue_check(dtype, case, Fr=2, H=12, W=12, C=728):
                        stats=stats)
     e = relerr(out, _nhwc(res))
     if case != 'b':
+        S.reduce_stats(stats, C)
         o = out.double().view(Fr, H, W, C).permute(0, 3, 1, 2)
         xh = (u.double() - v(bn.mean).double()) * v(bn.rstd).double()
-        e = max(e, relerr(stats[0], o.sum((0, 2, 3))), relerr(stats[1], (o * xh).sum((0, 2, 3))))
+        e = max(e, relerr(stats[0, 0], o.sum((0, 2, 3))), relerr(stats[0, 1], (o * xh).sum((0, 2, 3))))
     return e, TOL[dtype]
 
 
