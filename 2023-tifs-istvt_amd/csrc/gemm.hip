@@ -15,6 +15,7 @@
 // -> 8/16-byte epilogue accesses.  bf16: v_mfma_f32_16x16x32_bf16, transposed operands read with
 // ds_read_b64_tr_b16; f32: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "common.h"
+#include <cstdlib>
 
 #define EPI_NONE 0
 #define EPI_GELU_FWD 1   // C = u (pre-activation), C2 = gelu(u)
@@ -32,6 +33,7 @@ struct GemmArgs {
     int a_vec, b_vec;     // 16-byte vector loads legal for the operand
     float alpha;
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
+    int gm;               // gemm256: row-panels per tile group (L2 locality of the tile walk)
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -42,6 +44,7 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
 }
 
 #include "gemm256.h"
+#include "gemm256r.h"
 
 template <typename T> struct Tile { static constexpr int BK = 32; };
 template <> struct Tile<bf16_t> { static constexpr int BK = 64; };
@@ -229,6 +232,8 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epi = epi;
     a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
+    static const int gm_env = getenv("ISTVT_GEMM_GM") ? atoi(getenv("ISTVT_GEMM_GM")) : 0;
+    a.gm = gm_env > 0 ? gm_env : 4;       // sweep at the model's shapes: 4 is best or neutral everywhere
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + bk - 1) / bk) * bk;
     a.kper = kper;
@@ -243,8 +248,26 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         (a_kc ? (K % 8 == 0) : (M % 8 == 0 && N % 8 == 0))) {
         const int tiles = ((M + T256 - 1) / T256) * ((N + T256 - 1) / T256);
         dim3 grid(tiles, 1, splitk), block(512);
-        if (a_kc) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, stream, a);
+        static const int dbg = getenv("ISTVT_GEMM_DBG") ? atoi(getenv("ISTVT_GEMM_DBG")) : 0;
+        static const int ring = getenv("ISTVT_GEMM_RING") ? atoi(getenv("ISTVT_GEMM_RING")) : 1;
+        // measured at the model's shapes (same device, interleaved): the 4-slot ring is ~5 % faster for
+        // the k-contiguous case, the 2-stage kernel ~8 % faster for the transposed-operand case
+        if (dbg == 0 && (ring == 2 || (ring == 1 && a_kc))) {
+            if (a_kc) hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((gemm256r_kernel<true>), grid, block, 0, stream, a);
+        } else if (dbg == 0) {
+            if (a_kc) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, stream, a);
+        }
+#ifdef ISTVT_GEMM_DIAG
+        else if (dbg == 1) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, 0, stream, a);
+        else if (dbg == 2) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, 0, stream, a);
+        else if (dbg == 4) hipLaunchKernelGGL((gemm256_kernel<false, 4>), grid, block, 0, stream, a);
+        else if (dbg == 6) hipLaunchKernelGGL((gemm256_kernel<false, 6>), grid, block, 0, stream, a);
+        else if (dbg == 3) hipLaunchKernelGGL((gemm256_kernel<false, 3>), grid, block, 0, stream, a);
+        else if (dbg == 5) hipLaunchKernelGGL((gemm256_kernel<false, 5>), grid, block, 0, stream, a);
+#endif
+        else return ISTVT_ERR_SHAPE;
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, return launch_gemm<T>(a, a_kc, b_kc, splitk, stream));

@@ -159,7 +159,9 @@ __device__ __forceinline__ bf16x8 frag_tn(const char* img, int k0, int col16, in
 
 // ---- the kernel --------------------------------------------------------------------------------
 // TN = false: A [M][K], B [N][K] (k-contiguous).   TN = true: A [K][M], B [K][N] (row-contiguous).
-template <bool TN>
+// DBG (diagnostic builds only, selected with ISTVT_GEMM_DBG): 1 = no DMA inside the K loop,
+// 2 = no MFMA, 4 = no LDS fragment reads.  DBG = 0 is the product kernel.
+template <bool TN, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,7 +175,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
         id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
     }
-    const int bm0 = (id / tiles_n) * T256, bn0 = (id % tiles_n) * T256;
+    // tiles are walked in groups of `gm` row-panels, row-fastest inside a group: the ~32 workgroups an
+    // XCD runs concurrently then touch gm A-panels x 32/gm B-panels instead of 32/tiles_n x tiles_n
+    int tm, tn;
+    {
+        const int gm = p.gm > 0 ? p.gm : 1;
+        const int per_group = gm * tiles_n;
+        const int grp = id / per_group, idl = id % per_group;
+        const int rows_here = min(gm, tiles_m - grp * gm);
+        tm = grp * gm + idl % rows_here;
+        tn = idl / rows_here;
+    }
+    const int bm0 = tm * T256, bn0 = tn * T256;
     const int k_begin = blockIdx.z * p.kper;
     const int k_end = min(p.K, k_begin + p.kper);
     const bf16_t* A = (const bf16_t*)p.A;
@@ -210,12 +223,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK256, buf ^= 1) {
         __syncthreads();        // tile k0 has landed (vmcnt(0) is part of the barrier); the other stage is free
-        if (k0 + BK256 < k_end) stage(buf ^ 1, k0 + BK256);
+        if (!(DBG & 1) && k0 + BK256 < k_end) stage(buf ^ 1, k0 + BK256);
         const char* a_img = smem + buf * STAGE_BYTES;
         const char* b_img = a_img + STAGE_BYTES / 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 bf[4], af[8];
+            if (DBG & 4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bf[t] = __builtin_bit_cast(bf16x8, make_uint4(k0 + t, lane, t, ks));
+#pragma unroll
+                for (int t = 0; t < 8; ++t) af[t] = __builtin_bit_cast(bf16x8, make_uint4(k0 - t, lane, t, ks));
+            } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 bf[t] = TN ? frag_tn(b_img, ks * 32 + 8 * g, wn * 64 + t * 16, r)
@@ -224,11 +243,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             for (int t = 0; t < 8; ++t)
                 af[t] = TN ? frag_tn(a_img, ks * 32 + 8 * g, wm * 128 + t * 16, r)
                            : frag_nt(a_img, wm * 128 + t * 16 + r, ks * 4 + g);
+            }
+            if (DBG & 2) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(bf[t]));
+#pragma unroll
+                for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(af[t]));
+            } else {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            }
         }
     }
 
@@ -253,7 +280,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 *reinterpret_cast<f32x4*>(slab + (h * 16 + r) * ELD + nt * 16 + 4 * g) = acc[2 * pass + h][nt];
-        __syncthreads();
+        // the slab is private to this wavefront and a wavefront's DS operations execute in order, so
+        // a compiler-level fence is all the write->read (and the read->next-write) hand-off needs:
+        // the 8 wavefronts drift apart and one's stores overlap another's LDS transposes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3);
@@ -293,6 +325,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
