@@ -260,6 +260,9 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             else hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, stream, a);
         }
 #ifdef ISTVT_GEMM_DIAG
+        else if (dbg == 16) hipLaunchKernelGGL((gemm256r_kernel<false, 6>), grid, block, 0, stream, a);
+        else if (dbg == 12) hipLaunchKernelGGL((gemm256r_kernel<false, 2>), grid, block, 0, stream, a);
+        else if (dbg == 14) hipLaunchKernelGGL((gemm256r_kernel<false, 4>), grid, block, 0, stream, a);
         else if (dbg == 1) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, 0, stream, a);
         else if (dbg == 2) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, 0, stream, a);
         else if (dbg == 4) hipLaunchKernelGGL((gemm256_kernel<false, 4>), grid, block, 0, stream, a);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void r_stage_tn_tail(char* img, const bf16_t* base_k,
     }
 }
 
-template <bool TN>
+template <bool TN, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256r_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLOT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,17 +150,31 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(GemmArgs p) {
         const char* a_img = smem + (s & (NSLOT - 1)) * SLOT_BYTES;
         const char* b_img = a_img + SLOT_BYTES / 2;
         bf16x8 bf[4], af[8];
+        if (DBG & 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = __builtin_bit_cast(bf16x8, make_uint4(s + t, lane, t, 1));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) af[t] = __builtin_bit_cast(bf16x8, make_uint4(s - t, lane, t, 2));
+        } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             bf[t] = TN ? frag_tn(b_img, 8 * g, wn * 64 + t * 16, r) : r_frag_nt(b_img, wn * 64 + t * 16 + r, g);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             af[t] = TN ? frag_tn(a_img, 8 * g, wm * 128 + t * 16, r) : r_frag_nt(a_img, wm * 128 + t * 16 + r, g);
+        }
+        if (DBG & 2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(bf[t]));
+#pragma unroll
+            for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(af[t]));
+        } else {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
     }
 
     // ---- epilogue (identical to gemm256_kernel): 32-row slabs transposed through LDS

@@ -473,10 +473,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     __shared__ float sred[2][4][DW_CC];
     const int tid = threadIdx.x;
     const int tiles_x = (p.W + DW_TW - 1) / DW_TW, tiles_y = (p.H + DW_TH - 1) / DW_TH;
-    const int t = blockIdx.x;
-    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+    // 1-D grid, channel chunk fastest: the workgroups that share a pixel's 128-byte lines (its other
+    // channel chunks) are dispatched back to back and meet in L2 instead of re-fetching from HBM
+    const int nch = (p.C + DW_CC - 1) / DW_CC;
+    const long t = blockIdx.x / nch;
+    const int c0 = (int)(blockIdx.x % nch) * DW_CC;
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
     const long f = t / (tiles_x * tiles_y);
-    const int c0 = blockIdx.y * DW_CC;
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
     dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
 
@@ -587,14 +590,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     const int tid = threadIdx.x;
     const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
     const long ntiles = (long)Fr * tiles_x * tiles_y;
-    const int c0 = blockIdx.y * DW_CC;
+    const int nch = (C + DW_CC - 1) / DW_CC;                 // 1-D grid, channel chunk fastest (L2 sharing)
+    const int c0 = (int)(blockIdx.x % nch) * DW_CC;
     const int ch = tid & 3, c = c0 + ch * 8;
     float acc[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (long t = blockIdx.x / nch; t < ntiles; t += gridDim.x / nch) {
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const long f = t / (tiles_x * tiles_y);
         const int y0 = ty * DW_TH, x0 = tx * DW_TW;
@@ -657,7 +661,9 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
     a.msrc = msrc; a.m_bn = m_bn; a.mask_pre = mask_pre; a.mask_post = mask_post;
     a.addsrc = addsrc; a.Ha = Ha; a.Wa = Wa; a.st_s1 = st_s1; a.st_s2 = st_s2;
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
-    dim3 grid((unsigned)tiles, (C + DW_CC - 1) / DW_CC);
+    const long nblk = tiles * ((C + DW_CC - 1) / DW_CC);
+    if (nblk > 0x7fffffffL) return ISTVT_ERR_SHAPE;
+    dim3 grid((unsigned)nblk);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), grid, dim3(256), 0, stream, a));
     return istvt_check_launch();
 }
@@ -670,7 +676,7 @@ extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_
     long bx = 2048 / cy;
     if (bx < 1) bx = 1;
     if (bx > tiles) bx = tiles;
-    dim3 grid((unsigned)bx, cy);
+    dim3 grid((unsigned)(bx * cy));                        // slot-major, channel chunk fastest
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, dim3(256), 0, stream, (const T*)in,
                                              in_bn, in_relu, (const T*)dout, dw, Fr, H, W, C));
     return istvt_check_launch();
