@@ -86,15 +86,29 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
 }
 
 // ---- wave-level reductions (all 64 lanes get the result) ---------------------------------
+// DPP within each 16-lane row (quad_perm x2, row_half_mirror, row_mirror: no LDS crossbar), then
+// the four row totals are read through SGPRs (v_readlane) -- 6 ds_bpermute round trips per
+// reduction were the critical path of the one-wavefront-per-row LayerNorm kernels.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// the builtin is the INTEGER readlane: passing a float converts its VALUE; move the bits instead
+__device__ __forceinline__ float row_total(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror  -> every lane holds its row's sum
+    return (row_total(v, 0) + row_total(v, 16)) + (row_total(v, 32) + row_total(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(row_total(v, 0), row_total(v, 16)), fmaxf(row_total(v, 32), row_total(v, 48)));
 }
 
 // ---- MFMA traits: one logical K=32 step on a 16x16 tile ----------------------------------

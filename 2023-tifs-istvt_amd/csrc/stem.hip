@@ -429,7 +429,12 @@ extern "C" int istvt_col2im3x3(const void* dcol, const void* u, const float* bnp
 // ============================================================================================
 // depthwise 3x3, stride 1, pad 1 (SeparableConv2d.conv1, xception.py:43) with an LDS tile
 // ============================================================================================
-constexpr int DW_TH = 8, DW_TW = 16, DW_CC = 32;            // output tile: 8 x 16 pixels x 32 channels
+// output tile: 8 x 16 pixels x 64 channels.  64 channels = one 128-byte line per pixel (bf16): with
+// 32 (half lines) every line crossed the L2->CU path twice and the kernel ran at 1.3-1.5 TB/s.
+constexpr int DW_TH = 8, DW_TW = 16, DW_CC = 64;
+constexpr int DW_NCH = DW_CC / 8;                           // 8-channel chunks per tile
+constexpr int DW_PIXSTEP = 256 / DW_NCH;                    // pixels covered by one pass of the 256 threads
+constexpr int DW_ITEMS = DW_TH * DW_TW / DW_PIXSTEP;        // (pixel, chunk) items per thread
 constexpr int DW_LH = DW_TH + 2, DW_LW = DW_TW + 2;
 constexpr int DW_TILE_ELEMS = DW_LH * DW_LW * DW_CC;
 
@@ -449,15 +454,42 @@ struct DwArgs {
 template <typename T>
 __device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
                                              int W, int C, const float* bnp, int relu, int tid) {
-    constexpr int NVEC = DW_LH * DW_LW * (DW_CC / 8);
-    for (int i = tid; i < NVEC; i += 256) {
-        const int ch = i % (DW_CC / 8);
-        const int px = (i / (DW_CC / 8)) % DW_LW, py = i / ((DW_CC / 8) * DW_LW);
-        const int y = y0 - 1 + py, x = x0 - 1 + px, c = c0 + ch * 8;
+    constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
+    constexpr int NIT = (NVEC + 255) / 256;
+    // phase 1: issue every global load of the tile before touching any result (one dependent
+    // load->LDS-store round per loop iteration made the tile fill a chain of HBM latencies)
+    const int ch = tid % DW_NCH, c = c0 + ch * 8;          // 256 % DW_NCH == 0: same chunk every iteration
+    typename Mma<T>::frag raw[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        ok[it] = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
+        if (ok[it]) raw[it] = frag_load(in + ((f * H + y) * W + x) * C + c);
+    }
+    float mu[8], sc[8], be[8];
+    if (bnp && c < C) { load8(bnp + c, mu); load8(bnp + 2 * C + c, sc); load8(bnp + 3 * C + c, be); }
+    // phase 2: transform (BatchNorm pack, ReLU) and store
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        if (i >= NVEC) continue;
+        const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (y >= 0 && y < H && x >= 0 && x < W && c < C) {
-            load8(in + ((f * H + y) * W + x) * C + c, v);
-            if (bnp) bn_affine8(v, bnp, C, c);
+        if (ok[it]) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)raw[it][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = raw[it].v[j];
+            }
+            if (bnp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu[j]) * sc[j] + be[j];
+            }
             if (relu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -470,7 +502,7 @@ __device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
-    __shared__ float sred[2][4][DW_CC];
+    __shared__ float sred[2][4][DW_CC];   // [s1|s2][wave][channel]
     const int tid = threadIdx.x;
     const int tiles_x = (p.W + DW_TW - 1) / DW_TW, tiles_y = (p.H + DW_TH - 1) / DW_TH;
     // 1-D grid, channel chunk fastest: the workgroups that share a pixel's 128-byte lines (its other
@@ -483,7 +515,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
     dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
 
-    const int ch = tid & 3;                       // 8-channel chunk of this thread (same for both items)
+    const int ch = tid % DW_NCH;                  // 8-channel chunk of this thread (same for all its items)
     const int c = c0 + ch * 8;
     // weights are passed tap-major ([9][C]): a thread's 8 channels of one tap are one 32-byte load
     // (the PyTorch [C][9] order costs 72 scalar loads per thread and dominated the kernel)
@@ -501,8 +533,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 
     float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int pix = (tid >> 2) + 64 * k;
+    for (int k = 0; k < DW_ITEMS; ++k) {
+        const int pix = tid / DW_NCH + DW_PIXSTEP * k;
         const int py = pix / DW_TW, px = pix % DW_TW;
         const int y = y0 + py, x = x0 + px;
         if (y >= p.H || x >= p.W || c >= p.C) continue;
@@ -556,17 +588,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         store8((T*)p.out + off, acc);
     }
     if (p.st_s1) {
-        // reduce over the 16 pixels of a wave that share this channel chunk (lanes with equal tid&3)
+        // reduce over the pixels of a wave that share this channel chunk (lanes with equal tid % DW_NCH)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
-            for (int o = 4; o < 64; o <<= 1) {
+            for (int o = DW_NCH; o < 64; o <<= 1) {
                 st1[j] += __shfl_xor(st1[j], o, 64);
                 st2[j] += __shfl_xor(st2[j], o, 64);
             }
         }
         const int lane = tid & 63, wid = tid >> 6;
-        if (lane < 4) {
+        if (lane < DW_NCH) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { sred[0][wid][lane * 8 + j] = st1[j]; sred[1][wid][lane * 8 + j] = st2[j]; }
         }
@@ -586,13 +618,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
                                                               const T* __restrict__ dout, float* __restrict__ dw,
                                                               int Fr, int H, int W, int C) {
     __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
-    __shared__ float sred[4][4][72];
+    __shared__ float sred[4][DW_NCH][72];
     const int tid = threadIdx.x;
     const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
     const long ntiles = (long)Fr * tiles_x * tiles_y;
     const int nch = (C + DW_CC - 1) / DW_CC;                 // 1-D grid, channel chunk fastest (L2 sharing)
     const int c0 = (int)(blockIdx.x % nch) * DW_CC;
-    const int ch = tid & 3, c = c0 + ch * 8;
+    const int ch = tid % DW_NCH, c = c0 + ch * 8;
     float acc[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -606,8 +638,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
         dw_load_tile<T>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pix = (tid >> 2) + 64 * k;
+        for (int k = 0; k < DW_ITEMS; ++k) {
+            const int pix = tid / DW_NCH + DW_PIXSTEP * k;
             const int py = pix / DW_TW, px = pix % DW_TW;
             const int y = y0 + py, x = x0 + px;
             if (y >= H || x >= W || c >= C) continue;
@@ -629,17 +661,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
-            for (int o = 4; o < 64; o <<= 1) acc[t][j] += __shfl_xor(acc[t][j], o, 64);
+            for (int o = DW_NCH; o < 64; o <<= 1) acc[t][j] += __shfl_xor(acc[t][j], o, 64);
         }
     const int lane = tid & 63, wid = tid >> 6;
-    if (lane < 4) {
+    if (lane < DW_NCH) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) sred[wid][lane][t * 8 + j] = acc[t][j];
     }
     __syncthreads();
-    for (int o = tid; o < 4 * 72; o += 256) {
+    for (int o = tid; o < DW_NCH * 72; o += 256) {
         const int chunk = o / 72, rem = o % 72, tap = rem / 8, j = rem % 8;
         const int cc = c0 + chunk * 8 + j;
         if (cc < C)

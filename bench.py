@@ -52,7 +52,9 @@ def parse():
 def cpu_baseline(frames, size, depth):
     """oracle (kind "port"): one fwd+bwd of ONE clip of the benchmark geometry on the host cores."""
     from oracle import istvt_ref as R
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and then collapses) far below the 256 hardware threads of
+    # the GPU box's host on this small problem: 256 threads took 209 s for the one clip, so cap at 32
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     grid = R.stem_out_side(size)
     shapes = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
