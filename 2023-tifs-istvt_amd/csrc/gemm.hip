@@ -46,6 +46,12 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
 #include "gemm256.h"
 #include "gemm256r.h"
 
+// Smallest output edge sent to the 256x256 DMA kernels.  Narrow outputs (the stem's 64/128-channel
+// pointwise convs over ~3 M pixels, K <= 288) waste MFMA lanes in a 256-wide tile, but those GEMMs
+// are HBM-bound: what matters is streaming A once with full-line DMA and storing C in 16-byte
+// row segments, which the 128x128 register-staged kernel does not do.
+constexpr int ISTVT_G256_MIN = 64;
+
 template <typename T> struct Tile { static constexpr int BK = 32; };
 template <> struct Tile<bf16_t> { static constexpr int BK = 64; };
 
@@ -244,7 +250,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     const bool out16 = N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 &&
                        (!residual || (ldr % 8 == 0 && ((uintptr_t)residual % 16) == 0)) &&
                        (!C2 || ((uintptr_t)C2 % 16) == 0) && (!bias || ((uintptr_t)bias % 16) == 0);
-    if (dtype == DT_BF16 && a.a_vec && a.b_vec && out16 && M >= 192 && N >= 192 && a_kc == b_kc &&
+    if (dtype == DT_BF16 && a.a_vec && a.b_vec && out16 && M >= ISTVT_G256_MIN && N >= ISTVT_G256_MIN && a_kc == b_kc &&
         (a_kc ? (K % 8 == 0) : (M % 8 == 0 && N % 8 == 0))) {
         const int tiles = ((M + T256 - 1) / T256) * ((N + T256 - 1) / T256);
         dim3 grid(tiles, 1, splitk), block(512);

@@ -46,6 +46,7 @@ def _stream() -> int:
 # ------------------------------------------------------------------------------------------
 # fp32 master weight -> compute-dtype operand, cached per parameter version
 _wcache: dict = {}
+G256_MIN = 64          # smallest output edge routed to the 256x256 DMA GEMM (mirrors ISTVT_G256_MIN in gemm.hip)
 
 
 def cast(t: Tensor, dtype: torch.dtype) -> Tensor:
@@ -158,7 +159,7 @@ def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Opt
     dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
     epi = 2 if gelu_u is not None else 0
     c2 = _c(gelu_u) if gelu_u is not None else None
-    if wt is None and dy.dtype == torch.bfloat16 and M >= 192 and K >= 192 and N % 8 == 0:
+    if wt is None and dy.dtype == torch.bfloat16 and M >= G256_MIN and K >= G256_MIN and N % 8 == 0:
         wt = _transposed_operand(w)
     if wt is not None:
         gemm_raw(dy, N, True, wt, N, True, dx, K, M, K, N, C2=c2, epi=epi)
@@ -185,7 +186,7 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     dy, x = _c(dy), _c(x)
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
-    big = dy.dtype == torch.bfloat16 and N >= 192 and K >= 192 and N % 8 == 0 and K % 8 == 0
+    big = dy.dtype == torch.bfloat16 and N >= G256_MIN and K >= G256_MIN and N % 8 == 0 and K % 8 == 0
     splits = _pick_splitk(N, K, M, big)
     if big:
         # partial slabs + a reduce pass: every split of a tile finishes at the same moment, so
