@@ -34,6 +34,7 @@ struct GemmArgs {
     float alpha;
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
     int gm;               // gemm256: row-panels per tile group (L2 locality of the tile walk)
+    int flat_splits;      // > 0: 1-D grid of 8*tiles*ceil(splits/8) workgroups, reduction slice s runs on XCD s % 8
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -254,11 +255,17 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         (a_kc ? (K % 8 == 0) : (M % 8 == 0 && N % 8 == 0))) {
         const int tiles = ((M + T256 - 1) / T256) * ((N + T256 - 1) / T256);
         dim3 grid(tiles, 1, splitk), block(512);
+        a.flat_splits = 0;
+        static const int flat = getenv("ISTVT_WGRAD_FLAT") ? atoi(getenv("ISTVT_WGRAD_FLAT")) : 0;   // measured: no gain (profiles/README.md), off
+        if (flat && !a_kc && splitk >= 8 && out_mode == 3) {         // weight gradient: one reduction slice per XCD at a time
+            a.flat_splits = splitk;
+            grid = dim3(8 * tiles * ((splitk + 7) / 8), 1, 1);
+        }
         static const int dbg = getenv("ISTVT_GEMM_DBG") ? atoi(getenv("ISTVT_GEMM_DBG")) : 0;
         static const int ring = getenv("ISTVT_GEMM_RING") ? atoi(getenv("ISTVT_GEMM_RING")) : 1;
         // measured at the model's shapes (same device, interleaved): the 4-slot ring is ~5 % faster for
         // the k-contiguous case, the 2-stage kernel ~8 % faster for the transposed-operand case
-        if (dbg == 0 && (ring == 2 || (ring == 1 && a_kc))) {
+        if (dbg == 0 && ring >= 1 && a_kc) {
             if (a_kc) hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((gemm256r_kernel<true>), grid, block, 0, stream, a);
         } else if (dbg == 0) {

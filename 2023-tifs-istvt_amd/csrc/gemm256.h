@@ -171,7 +171,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + T256 - 1) / T256;
     const int nwg = tiles_n * tiles_m;
     int id = blockIdx.x;
-    {   // XCD-aware order (bijective): workgroups that share an XCD walk consecutive tiles
+    int zsplit = blockIdx.z;
+    if (p.flat_splits > 0) {
+        // split-K weight gradients: every tile of one reduction slice reads the same rows of dy and
+        // x, so a whole slice is given to ONE XCD (slice s -> XCD s % 8) and its tiles run together:
+        // the panels are fetched from HBM once per slice instead of once per tile row/column
+        // (PMC: 3x the algorithmic bytes with slices interleaved over XCDs).
+        const int xcd = id & 7, j = id >> 3;
+        zsplit = xcd + 8 * (j / nwg);
+        id = j % nwg;
+        if (zsplit >= p.flat_splits) return;
+    } else {   // XCD-aware order (bijective): workgroups that share an XCD walk consecutive tiles
         const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
         id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
     }
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         tn = idl / rows_here;
     }
     const int bm0 = tm * T256, bn0 = tn * T256;
-    const int k_begin = blockIdx.z * p.kper;
+    const int k_begin = zsplit * p.kper;
     const int k_end = min(p.K, k_begin + p.kper);
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* B = (const bf16_t*)p.B;
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     constexpr int ELD = 68;                                     // floats per slab row (64 + pad)
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * ELD);
     const float alpha = p.alpha;
-    const float* bias = (p.bias && blockIdx.z == 0) ? p.bias : nullptr;
+    const float* bias = (p.bias && zsplit == 0) ? p.bias : nullptr;
     const int colc = (lane & 7) * 8;
     const int n = bn0 + wn * 64 + colc;
     const bool n_ok = n < p.N;                                  // N % 8 == 0: a chunk is all in or all out
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += rv[j];
                     }
-                    if (p.out_f32) store8((float*)p.C + (long)blockIdx.z * p.slab + off, v);
+                    if (p.out_f32) store8((float*)p.C + (long)zsplit * p.slab + off, v);
                     else store8((bf16_t*)p.C + off, v);
                 }
             }

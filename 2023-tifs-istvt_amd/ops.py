@@ -84,6 +84,17 @@ def weight_as(w: Tensor, dtype: torch.dtype) -> Tensor:
 gemm_profile = None
 
 
+def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K) -> str:
+    """which kernel istvt_gemm launches for these operands (mirrors the dispatch rule in csrc/gemm.hip; the names
+    are the ones rocprofv3 prints, so bench.py's per-kernel timings can be checked against profiles/)."""
+    big = (A.dtype == torch.bfloat16 and bool(a_kc) == bool(b_kc) and M >= G256_MIN and N >= G256_MIN and N % 8 == 0
+           and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and (K % 8 == 0 if a_kc else M % 8 == 0))
+    if big:
+        return 'gemm256r_kernel<false, 0>' if a_kc else 'gemm256_kernel<true, 0>'
+    t = '__bf16' if A.dtype == torch.bfloat16 else 'float'
+    return 'gemm_kernel<%s, %s, %s>' % (t, str(bool(a_kc)).lower(), str(bool(b_kc)).lower())
+
+
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
              C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0):
@@ -101,7 +112,8 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
                                dtype_code(A), _stream())
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K)))
+        prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K),
+                     gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K)))
     _lib.check(rc, 'istvt_gemm')
 
 

@@ -49,8 +49,9 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(frames, size, depth):
-    """oracle (kind "port"): one fwd+bwd of ONE clip of the benchmark geometry on the host cores."""
+def cpu_baseline(frames, size, depth, clips=8):
+    """oracle (kind "port"): one fwd+bwd of a batch of `clips` clips of the benchmark geometry on the host cores
+    (bounded sample: ~1.6 s per clip on the GPU box's host -> ~10-15 s)."""
     from oracle import istvt_ref as R
     # torch's intra-op pool stops scaling (and then collapses) far below the 256 hardware threads of
     # the GPU box's host on this small problem: 256 threads took 209 s for the one clip, so cap at 32
@@ -60,15 +61,15 @@ def cpu_baseline(frames, size, depth):
     shapes = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
     shapes.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(frames, grid, depth=depth).items()})
     p = R.with_grad(R.random_params(shapes, seed=0))
-    x = torch.randn((1, frames, 3, size, size), generator=torch.Generator().manual_seed(0))
-    labels = torch.ones(1)
+    x = torch.randn((clips, frames, 3, size, size), generator=torch.Generator().manual_seed(0))
+    labels = torch.ones(clips)
     t0 = time.perf_counter()
     logits = R.xception_vidtr_forward(p, x, depth=depth)
     R.bce_with_logits(logits, labels).backward()
     dt = time.perf_counter() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 clip (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads, %.1f s'
-                      % (frames, size, size, depth, torch.get_num_threads(), dt)}
+    return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': 'one batch of %d clips (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads, %.1f s'
+                      % (clips, frames, size, size, depth, torch.get_num_threads(), dt)}
 
 
 def main():
@@ -142,24 +143,34 @@ def main():
         step()
         torch.cuda.synchronize(dev)
         recs, ops.gemm_profile = ops.gemm_profile, None
-        by = {}
-        for ev0, ev1, flops, variant, shape in recs:
-            d = by.setdefault(variant, [0.0, 0.0, 0])
+        by = {}                                   # rocprof kernel name -> [flops, seconds, launches]
+        for ev0, ev1, flops, variant, shape, kname in recs:
+            d = by.setdefault(kname, [0.0, 0.0, 0])
             d[0] += flops
             d[1] += ev0.elapsed_time(ev1) * 1e-3
             d[2] += 1
         tot_f = sum(d[0] for d in by.values())
         tot_t = sum(d[1] for d in by.values())
-        n = sum(d[2] for d in by.values())
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-        ach = tot_f / tot_t / 1e12
-        names = {(True, True): 'fwd(NT)', (True, False): 'dgrad(NN)', (False, False): 'wgrad(TN)'}
-        roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<%s> (all Linear / 1x1-conv / im2col-conv GEMMs)' % a.dtype,
-                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': None, 'launches': n, 'avg_launch_us': round(tot_t / n * 1e6, 2),
-                'algorithmic_gflop_per_launch': round(tot_f / n / 1e9, 3), 'gemm_time_ms_per_step': round(tot_t * 1e3, 3),
-                'by_variant': {names[k]: {'tflops': round(v[0] / v[1] / 1e12, 2), 'ms': round(v[1] * 1e3, 3), 'launches': v[2]}
-                               for k, v in by.items()}}
+        dom = max(by, key=lambda k: by[k][1])     # the kernel with the most time per step
+        f, t, n = by[dom]
+        ach = f / t / 1e12
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(ach / peak, 4), 'traffic': None, 'launches_per_step': n,
+                'avg_launch_us': round(t / n * 1e6, 2), 'algorithmic_gflop_per_launch': round(f / n / 1e9, 3),
+                'kernel_ms_per_step': round(t * 1e3, 3),
+                'all_gemm': {'tflops': round(tot_f / tot_t / 1e12, 2), 'ms_per_step': round(tot_t * 1e3, 3),
+                             'by_kernel': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'ms': round(v[1] * 1e3, 3),
+                                               'launches': v[2]} for k, v in by.items()}}}
+        # HBM traffic per launch is not measurable from inside the process: it comes from the committed PMC
+        # passes over this same command (profiles/pmc/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE)
+        pmc = os.path.join(ROOT, 'profiles', 'pmc', 'r01_pmc_whole_step_summary.json')
+        is_c2 = (a.batch, a.frames, a.size, a.depth, a.dtype) == (32, 8, 224, 12, 'bf16')
+        if is_c2 and os.path.exists(pmc):
+            rec = json.load(open(pmc)).get('void ' + dom)
+            if rec and 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
+                roof['traffic'] = round((2.0 * rec['FETCH_SIZE']['avg_KB'] + rec['WRITE_SIZE']['avg_KB']) * 1024)
+                roof['traffic_unit'] = 'bytes/launch (rocprofv3 --pmc, profiles/pmc/)'
 
     if rank == 0:
         clips = world * a.batch * a.steps
