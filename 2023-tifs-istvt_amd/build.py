@@ -29,11 +29,28 @@ def _newest_header():
 def _compile(src):
     obj = os.path.join(OBJ, src[:-4] + '.o')
     path = os.path.join(CSRC, src)
-    cmd = [HIPCC] + FLAGS + ['-c', path, '-o', obj]
+    cmd = [HIPCC] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', path, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-6000:]))
+    _check_no_spills(src, r.stderr)
     return obj
+
+
+# Kernels whose loads are inline-asm (the compiler does not know their results arrive late): a register spill
+# there would store a not-yet-landed value, silently.  The build fails instead.
+NO_SPILL_KERNELS = ('gemm256p_kernel',)
+
+
+def _check_no_spills(src, remarks):
+    name = None
+    for line in remarks.splitlines():
+        if 'Function Name:' in line:
+            name = line.split('Function Name:')[1].split()[0]
+        elif 'ScratchSize [bytes/lane]:' in line and name and any(k in name for k in NO_SPILL_KERNELS):
+            n = int(line.split('ScratchSize [bytes/lane]:')[1].split()[0])
+            if n != 0:
+                raise RuntimeError('%s: kernel %s spills %d bytes/lane to scratch; it must not (see build.py)' % (src, name, n))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

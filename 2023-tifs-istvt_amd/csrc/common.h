@@ -16,6 +16,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define ISTVT_OK 0
 #define ISTVT_ERR_DTYPE (-2)

@@ -44,8 +44,34 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
     return cdf + u * pdf;
 }
 
+// Branch-free erf for the bf16 epilogues (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute: 4 orders below
+// one bf16 ulp of gelu / gelu').  libm's erff is two divergent polynomial branches (~50 VALU operations when a
+// wavefront takes both); in the GELU epilogues that was ~0.17 ms of VALU per launch with the MFMA pipe idle.
+// exp(-x^2) is shared with the Gaussian of gelu'.  The fp32 parity kernels keep erff.
+__device__ __forceinline__ float erfc_pos_fast(float ax, float e /* exp(-ax*ax) */) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    return p * t * e;                                   // erfc(ax), ax >= 0
+}
+__device__ __forceinline__ float gelu_fast(float u) {
+    const float x = u * 0.70710678118654752440f, ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float erf_abs = 1.0f - erfc_pos_fast(ax, e);
+    return 0.5f * u * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_grad_fast(float u) {
+    const float x = u * 0.70710678118654752440f, ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);       // exp(-u*u/2)
+    const float erf_abs = 1.0f - erfc_pos_fast(ax, e);
+    return fmaf(u * 0.39894228040143267794f, e, 0.5f * (1.0f + copysignf(erf_abs, x)));
+}
+
 #include "gemm256.h"
 #include "gemm256r.h"
+#include "gemm256p.h"
 
 // Smallest output edge sent to the 256x256 DMA kernels.  Narrow outputs (the stem's 64/128-channel
 // pointwise convs over ~3 M pixels, K <= 288) waste MFMA lanes in a 256-wide tile, but those GEMMs
@@ -265,7 +291,23 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         static const int ring = getenv("ISTVT_GEMM_RING") ? atoi(getenv("ISTVT_GEMM_RING")) : 1;
         // measured at the model's shapes (same device, interleaved): the 4-slot ring is ~5 % faster for
         // the k-contiguous case, the 2-stage kernel ~8 % faster for the transposed-operand case
-        if (dbg == 0 && ring >= 1 && a_kc) {
+        static const int persist = getenv("ISTVT_GEMM_PERSIST") ? atoi(getenv("ISTVT_GEMM_PERSIST")) : 1;
+        const bool p_ok = out_mode == 0 && splitk == 1 && K > 96 && (!bias || alpha == 1.0f) &&!(epi == EPI_GELU_BWD && residual) && !(epi == EPI_GELU_FWD && residual);
+        if (dbg == 0 && persist && a_kc && p_ok) {
+            // persistent NT kernel: one workgroup per CU walks its tiles with the LDS ring kept full across tiles
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+                cus = n & ~7;
+            }
+            const int G = tiles < cus ? tiles : cus;
+            if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
+            else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
+            else if (residual) hipLaunchKernelGGL((gemm256p_kernel<0, true>), dim3(G), block, 0, stream, a);
+            else hipLaunchKernelGGL((gemm256p_kernel<0, false>), dim3(G), block, 0, stream, a);
+        } else if (dbg == 0 && ring >= 1 && a_kc) {
             if (a_kc) hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((gemm256r_kernel<true>), grid, block, 0, stream, a);
         } else if (dbg == 0) {

@@ -129,6 +129,29 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
 //            dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy        (fp32 atomics per block)
 // dy = dy1 (+ dy2[m] - dy2[m + P] when frame(m)+1 in [2, F-1])   [temporal variant, dy2 != null]
 // dx (+= dres when given: gradient arriving through the residual connection)
+// The loop is software-pipelined by one row: the loads of row m + nwaves are issued (as raw 16-byte chunks) before
+// row m is reduced, so a wavefront always has a row in flight behind the two dependent wave reductions.
+template <typename T> struct LnRaw;
+template <> struct LnRaw<bf16_t> { bf16x8 v; };
+template <> struct LnRaw<float> { float4 a, b; };
+__device__ __forceinline__ void raw_load(const bf16_t* p, LnRaw<bf16_t>& r) { r.v = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void raw_load(const float* p, LnRaw<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p);
+    r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void raw_f32(const LnRaw<bf16_t>& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
+}
+__device__ __forceinline__ void raw_f32(const LnRaw<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+template <typename T> struct LnBwdRow {
+    LnRaw<T> dy[LN_MAXCH], x[LN_MAXCH], t0[LN_MAXCH], t1[LN_MAXCH], rs[LN_MAXCH];
+    float mean, rstd;
+    bool sub;          // temporal variant: subtract dy2 of the next frame
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const float* __restrict__ mean_in,
@@ -148,60 +171,87 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
     const long N = (long)F * P;
-    for (long m = wave; m < M; m += nwaves) {
-        float dy[LN_MAXCH][8], xv[LN_MAXCH][8];
-        ln_row_load<T>(dy1 + m * D, D, lane, dy);
+    bool on[LN_MAXCH];
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c) on[c] = (lane + 64 * c) * 8 < D;
+
+    auto fetch = [&](LnBwdRow<T>& r, long m) {
+        r.sub = false;
         if (dy2) {
-            float t[LN_MAXCH][8];
-            ln_row_load<T>(dy2 + m * D, D, lane, t);
-#pragma unroll
-            for (int c = 0; c < LN_MAXCH; ++c)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dy[c][i] += t[c][i];
             const int f = (int)((m % N) / P);
-            if (f + 1 >= 2 && f + 1 < F) {
-                ln_row_load<T>(dy2 + (m + P) * D, D, lane, t);
-#pragma unroll
-                for (int c = 0; c < LN_MAXCH; ++c)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dy[c][i] -= t[c][i];
-            }
+            r.sub = f + 1 >= 2 && f + 1 < F;
         }
-        ln_row_load<T>(x + m * D, D, lane, xv);
-        const float mean = mean_in[m], rstd = rstd_in[m];
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            if (!on[c]) continue;
+            const long off = m * D + (lane + 64 * c) * 8;
+            raw_load(dy1 + off, r.dy[c]);
+            raw_load(x + off, r.x[c]);
+            if (dy2) {
+                raw_load(dy2 + off, r.t0[c]);
+                if (r.sub) raw_load(dy2 + off + (long)P * D, r.t1[c]);
+            }
+            if (dres) raw_load(dres + off, r.rs[c]);
+        }
+        r.mean = mean_in[m];
+        r.rstd = rstd_in[m];
+    };
+
+    LnBwdRow<T> cur, nxt;
+    if (wave < M) fetch(cur, wave);
+    for (long m = wave; m < M; m += nwaves) {
+        const bool more = m + nwaves < M;
+        if (more) fetch(nxt, m + nwaves);
+        float dy[LN_MAXCH][8], xv[LN_MAXCH][8];
+        const float mean = cur.mean, rstd = cur.rstd;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < LN_MAXCH; ++c) {
-            const int e = (lane + 64 * c) * 8;
+            if (on[c]) {
+                raw_f32(cur.dy[c], dy[c]);
+                raw_f32(cur.x[c], xv[c]);
+                if (dy2) {
+                    float t[8];
+                    raw_f32(cur.t0[c], t);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float xh = (e < D) ? (xv[c][i] - mean) * rstd : 0.f;
-                xv[c][i] = xh;
-                const float gdy = dy[c][i] * gm[c][i];
-                s1 += gdy;
-                s2 += gdy * xh;
-                ag[c][i] += dy[c][i] * xh;
-                ab[c][i] += dy[c][i];
+                    for (int i = 0; i < 8; ++i) dy[c][i] += t[i];
+                    if (cur.sub) {
+                        raw_f32(cur.t1[c], t);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) dy[c][i] -= t[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (xv[c][i] - mean) * rstd;
+                    xv[c][i] = xh;
+                    const float gdy = dy[c][i] * gm[c][i];
+                    s1 += gdy;
+                    s2 += gdy * xh;
+                    ag[c][i] += dy[c][i] * xh;
+                    ab[c][i] += dy[c][i];
+                }
             }
         }
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
 #pragma unroll
         for (int c = 0; c < LN_MAXCH; ++c) {
-            const int e = (lane + 64 * c) * 8;
-            if (e < D) {
+            if (on[c]) {
+                const int e = (lane + 64 * c) * 8;
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = rstd * (dy[c][i] * gm[c][i] - s1 - xv[c][i] * s2);
                 if (dres) {
                     float rr[8];
-                    load8(dres + m * D + e, rr);
+                    raw_f32(cur.rs[c], rr);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] += rr[i];
                 }
                 store8(dx + m * D + e, o);
             }
         }
+        if (more) cur = nxt;
     }
     // block reduction of the parameter gradients, then one atomic per column per block
 #pragma unroll

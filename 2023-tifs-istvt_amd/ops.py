@@ -7,6 +7,7 @@ device: there is deliberately no CPU path.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -84,12 +85,17 @@ def weight_as(w: Tensor, dtype: torch.dtype) -> Tensor:
 gemm_profile = None
 
 
-def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K) -> str:
+def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residual=None, bias=None, out_mode=0,
+                     splitk=1, alpha=1.0) -> str:
     """which kernel istvt_gemm launches for these operands (mirrors the dispatch rule in csrc/gemm.hip; the names
     are the ones rocprofv3 prints, so bench.py's per-kernel timings can be checked against profiles/)."""
     big = (A.dtype == torch.bfloat16 and bool(a_kc) == bool(b_kc) and M >= G256_MIN and N >= G256_MIN and N % 8 == 0
            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and (K % 8 == 0 if a_kc else M % 8 == 0))
     if big:
+        persistent = (a_kc and out_mode == 0 and splitk == 1 and K > 96 and (bias is None or alpha == 1.0)
+                      and not (epi != 0 and residual is not None) and os.environ.get('ISTVT_GEMM_PERSIST', '1') != '0')
+        if persistent:
+            return 'gemm256p_kernel<%d, %s>' % (epi, 'true' if (epi == 0 and residual is not None) else 'false')
         return 'gemm256r_kernel<false, 0>' if a_kc else 'gemm256_kernel<true, 0>'
     t = '__bf16' if A.dtype == torch.bfloat16 else 'float'
     return 'gemm_kernel<%s, %s, %s>' % (t, str(bool(a_kc)).lower(), str(bool(b_kc)).lower())
@@ -113,7 +119,8 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K),
-                     gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K)))
+                     gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi, residual, bias, out_mode,
+                                      splitk, alpha)))
     _lib.check(rc, 'istvt_gemm')
 
 
