@@ -72,6 +72,7 @@ __device__ __forceinline__ float gelu_grad_fast(float u) {
 #include "gemm256.h"
 #include "gemm256r.h"
 #include "gemm256p.h"
+#include "gemm256q.h"
 
 // Smallest output edge sent to the 256x256 DMA kernels.  Narrow outputs (the stem's 64/128-channel
 // pointwise convs over ~3 M pixels, K <= 288) waste MFMA lanes in a 256-wide tile, but those GEMMs
@@ -303,7 +304,30 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 cus = n & ~7;
             }
             const int G = tiles < cus ? tiles : cus;
-            if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
+            static const int qk = getenv("ISTVT_GEMM_Q") ? atoi(getenv("ISTVT_GEMM_Q")) : 1;
+#ifdef ISTVT_GEMM_DIAG
+            static const int qdbg = getenv("ISTVT_GEMM_QDBG") ? atoi(getenv("ISTVT_GEMM_QDBG")) : 0;
+            if (qdbg && epi == 0 && !residual) {
+                switch (qdbg) {
+                    case 1: hipLaunchKernelGGL((gemm256q_kernel<0, false, 1>), dim3(G), block, 0, stream, a); break;
+                    case 2: hipLaunchKernelGGL((gemm256q_kernel<0, false, 2>), dim3(G), block, 0, stream, a); break;
+                    case 3: hipLaunchKernelGGL((gemm256q_kernel<0, false, 3>), dim3(G), block, 0, stream, a); break;
+                    case 4: hipLaunchKernelGGL((gemm256q_kernel<0, false, 4>), dim3(G), block, 0, stream, a); break;
+                    case 5: hipLaunchKernelGGL((gemm256q_kernel<0, false, 5>), dim3(G), block, 0, stream, a); break;
+                    case 6: hipLaunchKernelGGL((gemm256q_kernel<0, false, 6>), dim3(G), block, 0, stream, a); break;
+                    case 7: hipLaunchKernelGGL((gemm256q_kernel<0, false, 7>), dim3(G), block, 0, stream, a); break;
+                    default: hipLaunchKernelGGL((gemm256q_kernel<0, false, 8>), dim3(G), block, 0, stream, a); break;
+                }
+                return istvt_check_launch();
+            }
+#endif
+            const bool q_ok = (long)M * lda * 2 < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K > 64;
+            if (qk && q_ok) {       // 64-deep K tiles in 128-byte-row units, two wave groups in ping-pong (gemm256q.h)
+                if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
+                else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
+                else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), dim3(G), block, 0, stream, a);
+                else hipLaunchKernelGGL((gemm256q_kernel<0, false>), dim3(G), block, 0, stream, a);
+            } else if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
             else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
             else if (residual) hipLaunchKernelGGL((gemm256p_kernel<0, true>), dim3(G), block, 0, stream, a);
             else hipLaunchKernelGGL((gemm256p_kernel<0, false>), dim3(G), block, 0, stream, a);

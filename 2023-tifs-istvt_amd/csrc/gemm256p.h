@@ -29,7 +29,10 @@ constexpr int PSLAB_BYTES = 4096;
 
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
     u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+    // s_nop 4: the compiler does not know this statement is a VMEM instruction, so it does not pad the 5 wait states a
+    // VMEM read of an SGPR needs after a VALU wrote it (v_readfirstlane of a descriptor word, v_readlane of a spilled
+    // scalar offset): without them the load went out with the PREVIOUS value of the scalar offset (seen on gfx950).
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
     return v;
 }
 // wait until at most 4*n operations are outstanding (n = 0, 1, 2; uniform)

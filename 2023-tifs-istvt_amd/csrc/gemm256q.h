@@ -1,0 +1,392 @@
+// gemm256q: persistent 256x256 bf16 NT GEMM with 64-deep K tiles staged as four 16 KiB UNITS of 128-byte rows,
+// consumed by two wave groups that alternate between a load slot and a 32-MFMA slot (ping-pong).
+//
+// Why (measured with tools/dma_probe.hip on MI355X, one workgroup per CU streaming the FF1 panels into LDS,
+// no MFMA, no LDS reads):
+//      row piece / row stride            TB/s chip-wide
+//      64 B  (32-deep step) / 1456 B         10.4        <- gemm256r / gemm256p at K = 728
+//      64 B                 / 1536 B         15.0
+//      128 B (64-deep)      / 1456 B         14.6
+//      128 B                / 1536 B         22.5
+// The LDS-DMA is priced per cache line touched in the CU's address path, not per byte and not by latency (ring
+// depth changes nothing): a 64-byte piece of a 1456-byte-stride row touches up to two lines for half a line of
+// data, and a 256x256 tile needs 19.6 TB/s of staging at the MFMA peak.  Hence whole 128-byte lines per row and
+// step (BK = 64) and operands with line-aligned row strides (ops.py pads 728 -> 768, 2912 -> 2944).
+// In-kernel stamps of the first version (16-MFMA slots) then showed the slot, not the DMA, as the limit: a slot
+// took ~445 cycles for 256 cycles of MFMA because ONE in-order wavefront needs ~5 cycles per instruction and the
+// load slot carried ~45 of them plus the barrier round trip; so the slots are now 32 MFMA deep and the producer
+// works from two whole-matrix buffer descriptors (tile / half / k position in the scalar offset, which gfx950
+// includes in the range check -- tools/rc_probe) instead of rebuilding a descriptor per unit.
+//
+// Units of K tile kt, in stream order u = 4 kt + j, slot u & 7 (8 slots x 16 KiB = 128 KiB):
+//      j = 0  AL  A rows   0..127        j = 1  BL  B rows (C columns)   0..127
+//      j = 2  BH  B rows 128..255        j = 3  AH  A rows 128..255
+// image [128 rows][64 k], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) (swizzle on the DMA source).
+// Wavefront (wm, wn) = (wave >> 2, wave & 3) owns C rows {h*128 + wm*64 + 0..63, h = 0, 1} and C columns
+// wn*64 + 0..63 (inside ONE B half): 8 x 4 accumulator tiles of 16x16.  A K tile is two phases of 32 MFMA:
+//      phase A (p = 2 kt)      AL x B   needs AL and BL|BH    reads 8 A + 8 B fragments
+//      phase B (p = 2 kt + 1)  AH x B   needs AH              reads 8 A fragments (B stays in registers)
+// Every phase is a load slot L (the phase's ds_reads, the DMA of the unit pair 2p+6, 2p+7, the counted vmcnt for
+// the NEXT phase, lgkmcnt(0)) and an MFMA slot C, each closed by an s_barrier.  Waves 4..7 run one barrier behind
+// waves 0..3 inside a tile, so on every SIMD one wave is in L while its partner is in C; one extra barrier at either
+// end of the tile re-aligns the groups so that both run the epilogue together.
+//
+// Hazards (unit U is issued in L of phase floor((U-6)/2) into the slot of unit U-8):
+//   * WAR: unit U-8 is last read in phase r: AL, BL, BH of kt in 2kt, AH in 2kt+1.  The later group reads in slot
+//     2r+1 and waits lgkmcnt(0) before that slot's barrier; the earlier group overwrites in slot 2p' >= 2r+2:
+//     AL(kt+2), BL(kt+2) in phase 2kt+1, BH(kt+1), AH(kt+1) in phase 2kt.
+//   * RAW: phase q's units are waited for (own pieces, counted vmcnt) at the end of L of phase q-1 by BOTH groups,
+//     i.e. before the barriers that precede slot 2q, the first slot in which anybody reads them.
+//   * vmcnt: phase 2kt+1 needs AH = 4kt+3, issued by then <= 4kt+7: 8 pieces may stay in flight; phase 2kt+2 needs
+//     units <= 4kt+6, issued <= 4kt+9: 6 pieces.  Fewer exist only at the end of the stream.
+#pragma once
+
+constexpr int QU_BYTES = 16384;
+constexpr int QNU = 8;
+
+__device__ __forceinline__ void wait_vm_n(int n) {      // uniform n; vmcnt(n) for the counts this kernel uses
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ void slot_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+}
+
+// EPI / SIDE as in gemm256p_kernel.  Requires K > 64 (two or more K tiles), 16-byte aligned rows, and operands
+// smaller than 2 GiB (32-bit buffer offsets).
+// DBG (diagnostic builds only, -DISTVT_GEMM_DIAG + ISTVT_GEMM_QDBG=n): 1 = no DMA inside the K loop, 2 = no MFMA,
+// 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2.
+template <int EPI, bool SIDE, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
+    constexpr bool HAS_SIDE = SIDE || EPI == EPI_GELU_BWD;
+    constexpr bool LATE_Q3 = EPI == EPI_GELU_BWD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lda = (int)p.lda, ldb = (int)p.ldb, ldc = (int)p.ldc;
+
+    const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + T256 - 1) / T256;
+    const int nwg = tiles_n * tiles_m;
+    const int G = gridDim.x;
+    const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
+    const int nkt = (p.K + 63) >> 6;
+    const int total_u = my_tiles * nkt * 4;
+
+    auto tile_origin = [&](int i, int& bm0, int& bn0) {
+        int id = (int)blockIdx.x + i * G;
+        const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+        const int gm = p.gm > 0 ? p.gm : 1;
+        const int per_group = gm * tiles_n;
+        const int grp = id / per_group, idl = id % per_group;
+        const int rows_here = min(gm, tiles_m - grp * gm);
+        bm0 = (grp * gm + idl % rows_here) * T256;
+        bn0 = (idl / rows_here) * T256;
+    };
+
+    constexpr unsigned OOB = 0x80000000u, WINDOW = 0x7fffffffu, RSRC_FLAGS = 0x00020000u;
+    auto uni_ptr = [](const void* q) -> char* {          // provably wave-uniform to the compiler (no waterfall loops)
+        const unsigned long long u = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (char*)(((unsigned long long)hi << 32) | lo);
+    };
+    // ---- producer: the unit stream -------------------------------------------------------------------
+    // piece i of a unit = half-rows i*64 + wave*8 + (lane >> 3); both pieces share the swizzled chunk.
+    // One descriptor per operand over the whole matrix: rows past M / N are past num_records and read as zeros.
+    const int hr0 = wave * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((hr0 >> 1) & 7);
+    unsigned va[2], vb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        va[i] = (unsigned)((hr0 + 64 * i) * lda * 2 + chunk * 16);
+        vb[i] = (unsigned)((hr0 + 64 * i) * ldb * 2 + chunk * 16);
+    }
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.A), 0, p.M * lda * 2, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.B), 0, p.N * ldb * 2, RSRC_FLAGS);
+    int P = 0, p_s = 0, p_i = 0;
+    int a_org = 0, b_org = 0;                     // byte offsets of the producer's tile inside A / B
+    auto p_setup = [&](int i) {
+        int bm0, bn0;
+        tile_origin(i, bm0, bn0);
+        a_org = bm0 * lda * 2;
+        b_org = bn0 * ldb * 2;
+    };
+    // units P, P+1 of K tile p_s: J0 = 0 -> (AL, BL), J0 = 2 -> (BH, AH)
+    auto issue_pair = [&](const int J0) {
+        if (P >= total_u) return;
+        if ((DBG & 1) && P >= 6) { P += 2; return; }
+        char* img = smem + (P & (QNU - 1)) * QU_BYTES + wave * 1024;
+        const int k0 = p_s * 64;
+        // reduction tail: chunks past K get the top offset bit -> out of range -> zeros (a select, never a branch)
+        const unsigned deadbit = (chunk * 8 >= p.K - k0) ? OOB : 0u;
+        const int sa = a_org + k0 * 2 + (J0 == 2 ? 128 * lda * 2 : 0);
+        const int sb = b_org + k0 * 2 + (J0 == 2 ? 128 * ldb * 2 : 0);
+        if (J0 == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + i * 8192), 16, va[i] | deadbit, sa, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, vb[i] | deadbit, sb, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + i * 8192), 16, vb[i] | deadbit, sb, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, va[i] | deadbit, sa, 0, 0);
+        }
+        P += 2;
+        if (J0 == 2 && ++p_s == nkt) {
+            p_s = 0;
+            if (++p_i < my_tiles) p_setup(p_i);
+        }
+    };
+    if (my_tiles > 0) p_setup(0);
+    issue_pair(0); issue_pair(2); issue_pair(0);           // units 0..5
+    wait_vm_n(min(6, 2 * max(0, total_u - 3)));            // units 0..2 landed (own pieces)
+    slot_barrier();
+
+    float* slab = reinterpret_cast<float*>(smem + QNU * QU_BYTES + wave * PSLAB_BYTES);
+    const float alpha = p.alpha;
+    const int colc = (lane & 7) * 8;
+    const int erow = lane >> 3;
+    const char* side = EPI == EPI_GELU_BWD ? (const char*)p.C2 : (const char*)p.residual;
+    const int lds_ = EPI == EPI_GELU_BWD ? ldc : (int)p.ldr;
+    const int row_w = wm * 64 + erow, col_w = wn * 64 + colc;       // this lane's first row / column inside the tile
+    // fragment address inside a unit: row (.. + r) * 128 + ((kh*4 + g) ^ ((r >> 1) & 7)) * 16; kh = 1 flips bit 6
+    const unsigned la0 = (unsigned)(r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
+    const unsigned la_a[2] = {la0 + wm * 64 * 128, (la0 ^ 64u) + wm * 64 * 128};          // + unit base + t * 2048
+    const unsigned la_b[2] = {la0 + (wn & 1) * 64 * 128, (la0 ^ 64u) + (wn & 1) * 64 * 128};
+    const int b_unit = 1 + (wn >> 1);
+
+    int KT = 0;                                // K tiles consumed so far (stream-wide): slot parity
+    int U0 = 0;                                // first unit of the current K tile
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int bm0, bn0;
+        tile_origin(ti, bm0, bn0);
+        // (the output / side descriptors are built where they are used: live across the K loop they cost 12 SGPRs)
+        auto side_rs = [&]() {
+            return __builtin_amdgcn_make_buffer_rsrc(
+                uni_ptr(HAS_SIDE ? side + ((long)bm0 * lds_ + bn0) * 2 : (const char*)p.C), 0, WINDOW, RSRC_FLAGS);
+        };
+        bool n_ok; int rows_left; unsigned c_off, s_off;
+        auto lane_offsets = [&]() {
+            int row_o = row_w, col_o = col_w;
+            asm volatile("" : "+v"(row_o), "+v"(col_o));
+            n_ok = bn0 + col_o < p.N;
+            rows_left = p.M - bm0 - row_o;
+            c_off = n_ok ? (unsigned)((row_o * ldc + col_o) * 2) : OOB;
+            s_off = n_ok ? (unsigned)((row_o * lds_ + col_o) * 2) : OOB;
+        };
+        // rows of epilogue piece idx = pass*2 + it (pass = accumulator row tile mt, it = 8-row half of it), relative
+        // to row_w: (mt >> 2) * 128 + (mt & 3) * 16 + it * 8
+#define QRB(idx) ((((idx) >> 3) * 128) + ((((idx) >> 1) & 3) * 16) + (((idx) & 1) * 8))
+        u32x4 sv[16];
+        auto fetch_side = [&](int quarter) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = quarter * 4 + q;
+                const int rb = QRB(idx);
+                sv[idx] = buf_load16(side_rs(), rb < rows_left ? s_off : OOB, rb * lds_ * 2);
+            }
+        };
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        unsigned long long t_stamp[3];
+        if (DBG & 8) t_stamp[0] = __builtin_amdgcn_s_memtime();
+        if (wm == 1) slot_barrier();           // stagger: waves 4..7 run one slot behind inside the tile
+
+        auto ktile = [&](const bool first, const bool last) {
+            const char* ubase = smem + (KT & 1) * 4 * QU_BYTES;
+            const char* ua_lo = ubase;
+            const char* ua_hi = ubase + 3 * QU_BYTES;
+            const char* ub = ubase + b_unit * QU_BYTES;
+            bf16x8 af[4][2], bq[4][2];
+            auto mma = [&](const int mt0) {
+                if (DBG & 2) {
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { asm volatile("" ::"v"(af[t][kh])); asm volatile("" ::"v"(bq[t][kh])); }
+                    return;
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt0 + t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt0 + t][nt], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            auto load_a = [&](const char* base) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (DBG & 4) {
+                        af[t][0] = __builtin_bit_cast(bf16x8, make_uint4(KT + t, lane, t, 1));
+                        af[t][1] = __builtin_bit_cast(bf16x8, make_uint4(KT - t, lane, t, 2));
+                    } else {
+                        af[t][0] = *reinterpret_cast<const bf16x8*>(base + la_a[0] + t * 2048);
+                        af[t][1] = *reinterpret_cast<const bf16x8*>(base + la_a[1] + t * 2048);
+                    }
+                }
+            };
+            // ---- phase A: AL x B
+            load_a(ua_lo);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (DBG & 4) {
+                    bq[t][0] = __builtin_bit_cast(bf16x8, make_uint4(KT + t, lane, t, 3));
+                    bq[t][1] = __builtin_bit_cast(bf16x8, make_uint4(KT - t, lane, t, 4));
+                } else {
+                    bq[t][0] = *reinterpret_cast<const bf16x8*>(ub + la_b[0] + t * 2048);
+                    bq[t][1] = *reinterpret_cast<const bf16x8*>(ub + la_b[1] + t * 2048);
+                }
+            }
+            if (first && p.bias) {
+                // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped);
+                // issued BEFORE this slot's units, so that the wait at the end of phase B covers it
+                const int col = min(bn0 + wn * 64 + lane, p.N - 1);
+                __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)slab, 4, 0, 0);
+            }
+            issue_pair(2);                                                   // units U0+6, U0+7
+            // unit U0+3 (AH) landed: all but the 4 younger units (8 pieces); fewer exist only when the stream ends
+            if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
+            slot_barrier();
+            mma(0);
+            slot_barrier();
+            // ---- phase B: AH x B
+            load_a(ua_hi);
+            issue_pair(0);                                                   // units U0+8, U0+9
+            if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
+            // units <= U0+6 (the next K tile's AL, BL, BH) landed; the side loads just issued are younger still
+            if (total_u - 1 - (U0 + 6) >= 3) {
+                if (last && HAS_SIDE) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                wait_vm_n(2 * max(0, total_u - 1 - (U0 + 6)) + ((last && HAS_SIDE) ? 4 : 0));
+            }
+            slot_barrier();
+            mma(4);
+            slot_barrier();
+            ++KT;
+            U0 += 4;
+        };
+        ktile(true, false);
+        if (p.bias) {
+            // the bias DMA was issued in phase A of the first K tile, before units U0-4+6..9: phase B's wait covered it
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 bqv = *reinterpret_cast<const f32x4*>(slab + nt * 16 + 4 * g);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) acc[mt][nt] += bqv;
+            }
+        }
+        for (int s = 1; s < nkt - 1; ++s) ktile(false, false);
+        ktile(false, true);
+
+        if (wm == 0) slot_barrier();           // re-align the two groups: both run the epilogue together
+        if (DBG & 8) t_stamp[1] = __builtin_amdgcn_s_memtime();
+
+        // ---- epilogue: wave-local, 8 passes of 16 rows through this wave's slab (as gemm256p_kernel) ----
+        const long c_org = ((long)bm0 * ldc + bn0) * 2;
+        const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr((char*)p.C + c_org), 0, WINDOW, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t c2_rs = __builtin_amdgcn_make_buffer_rsrc(
+            uni_ptr(EPI == EPI_GELU_FWD ? (char*)p.C2 + c_org : (char*)p.C), 0, WINDOW, RSRC_FLAGS);
+        if (HAS_SIDE) { fetch_side(1); if (!LATE_Q3) { fetch_side(2); fetch_side(3); } }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int re = lane_e & 15, ge = lane_e >> 4, rowe = lane_e >> 3, l7 = lane_e & 7;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            if (LATE_Q3 && pass == 2) fetch_side(2);
+            if (LATE_Q3 && pass == 4) fetch_side(3);
+            if (HAS_SIDE && (pass & 1) == 0) {
+                u32x4 &s0 = sv[pass * 2], &s1 = sv[pass * 2 + 1], &s2 = sv[pass * 2 + 2], &s3 = sv[pass * 2 + 3];
+                if (!LATE_Q3)
+                    asm volatile("s_waitcnt vmcnt(12)" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)::"memory");
+                else if (pass == 0 || pass == 6)
+                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(8)" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)::"memory");
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(slab + re * 64 + (((nt * 4 + ge) ^ re) << 2)) = acc[pass][nt];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            u32x4 held[2], held2[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + rowe;
+                const int rb = QRB(pass * 2 + it);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7) ^ row) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7 + 1) ^ row) << 2));
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j] * alpha; v[4 + j] = hi[j] * alpha; }
+                const unsigned voff = rb < rows_left ? c_off : OOB;
+                const int soff = rb * ldc * 2;
+                if (EPI == EPI_GELU_BWD) {
+                    const bf16x8 u = __builtin_bit_cast(bf16x8, sv[pass * 2 + it]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_fast((float)u[j]);
+                } else if (SIDE) {
+                    const bf16x8 u = __builtin_bit_cast(bf16x8, sv[pass * 2 + it]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)u[j];
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+                held[it] = __builtin_bit_cast(u32x4, o);
+                __builtin_amdgcn_raw_buffer_store_b128(held[it], c_rs, voff, soff, 0);
+                if (EPI == EPI_GELU_FWD) {
+                    bf16x8 o2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o2[j] = (bf16_t)gelu_fast(v[j]);
+                    held2[it] = __builtin_bit_cast(u32x4, o2);
+                    __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, 0);
+                }
+            }
+            // STORE-DATA HAZARD, see gemm256p.h
+            if (EPI == EPI_GELU_FWD)
+                asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1]), "+v"(held2[0]), "+v"(held2[1])::"memory");
+            else
+                asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1])::"memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        }
+#undef QRB
+        if (DBG & 8) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_stamp[2] = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && lane == 0 && ti < 16) {
+                unsigned long long* d = (unsigned long long*)p.C2 + (wave * 16 + ti) * 3;
+                d[0] = t_stamp[0]; d[1] = t_stamp[1]; d[2] = t_stamp[2];
+            }
+        }
+    }
+}

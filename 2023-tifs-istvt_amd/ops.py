@@ -95,7 +95,11 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
         persistent = (a_kc and out_mode == 0 and splitk == 1 and K > 96 and (bias is None or alpha == 1.0)
                       and not (epi != 0 and residual is not None) and os.environ.get('ISTVT_GEMM_PERSIST', '1') != '0')
         if persistent:
-            return 'gemm256p_kernel<%d, %s>' % (epi, 'true' if (epi == 0 and residual is not None) else 'false')
+            side = 'true' if (epi == 0 and residual is not None) else 'false'
+            q_ok = M * lda * 2 < 0x7fffffff and N * ldb * 2 < 0x7fffffff and K > 64
+            if q_ok and os.environ.get('ISTVT_GEMM_Q', '1') != '0':
+                return 'gemm256q_kernel<%d, %s, 0>' % (epi, side)
+            return 'gemm256p_kernel<%d, %s>' % (epi, side)
         return 'gemm256r_kernel<false, 0>' if a_kc else 'gemm256_kernel<true, 0>'
     t = '__bf16' if A.dtype == torch.bfloat16 else 'float'
     return 'gemm_kernel<%s, %s, %s>' % (t, str(bool(a_kc)).lower(), str(bool(b_kc)).lower())
