@@ -15,15 +15,15 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 # name -> argtypes (all return int).  Mirrors include/istvt_hip.h one to one.
 SIGNATURES = {
     'istvt_gemm': [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, I, I, I, F, I, P],
-    'istvt_layernorm_fwd': [P, P, P, P, P, P, L, I, F, I, P],
-    'istvt_layernorm_fwd_diff': [P, P, P, P, P, P, P, I, I, I, I, F, I, P],
-    'istvt_layernorm_bwd': [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
+    'istvt_layernorm_fwd': [P, L, P, P, P, L, P, P, L, I, F, I, P],
+    'istvt_layernorm_fwd_diff': [P, L, P, P, P, L, P, L, P, P, I, I, I, I, F, I, P],
+    'istvt_layernorm_bwd': [P, L, P, L, P, L, P, P, P, P, L, P, L, P, P, L, I, I, I, I, P],
     'istvt_attn_spatial_fwd': [P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_bwd': [P, P, P, P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_temporal_fwd': [P, P, P, I, I, I, I, I, F, I, P],
     'istvt_attn_temporal_bwd': [P, P, P, P, P, I, I, I, I, I, F, I, P],
-    'istvt_tokens_fwd': [P, P, P, P, P, I, I, I, I, I, I, P],
-    'istvt_tokens_bwd': [P, P, P, P, P, I, I, I, I, I, I, P],
+    'istvt_tokens_fwd': [P, P, P, P, P, L, I, I, I, I, I, I, P],
+    'istvt_tokens_bwd': [P, L, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],
     'istvt_stats_replicas': [],
     'istvt_stats_reduce': [P, I, P],
@@ -44,6 +44,7 @@ SIGNATURES = {
     'istvt_splitk_reduce': [P, I, L, P, P],
     'istvt_colsum': [P, P, L, I, L, I, P],
     'istvt_cast': [P, I, P, I, L, P],
+    'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
 }
 
 _lib = None

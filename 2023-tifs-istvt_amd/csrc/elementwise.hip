@@ -51,7 +51,7 @@ template <typename T>
 __global__ __launch_bounds__(128) void tokens_fwd_kernel(const T* __restrict__ feats, const float* __restrict__ space,
                                                          const float* __restrict__ temporal,
                                                          const float* __restrict__ pos, T* __restrict__ x, int B,
-                                                         int F, int P, int D, int pos_rows) {
+                                                         int F, int P, int D, int pos_rows, long ldx) {
     const long row = blockIdx.x;                 // over B*F*P
     const int p = (int)(row % P);
     const int f = (int)((row / P) % F);
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(128) void tokens_fwd_kernel(const T* __restrict__ f
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] += pe[i];
         }
-        store8(x + row * D + e, o);
+        store8(x + row * ldx + e, o);
     }
 }
 
@@ -80,14 +80,14 @@ template <typename T>
 __global__ __launch_bounds__(128) void tokens_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dfeats,
                                                          float* __restrict__ dspace, float* __restrict__ dtemporal,
                                                          float* __restrict__ dpos, int B, int F, int P, int D,
-                                                         int pos_rows) {
+                                                         int pos_rows, long lddx) {
     const int p = blockIdx.x, f = blockIdx.y;
     const int hw = P - 1, Tn = F - 1;
     for (int e = threadIdx.x * 8; e < D; e += 128 * 8) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (long b = 0; b < B; ++b) {
             float v[8];
-            load8(dx + ((b * F + f) * P + p) * D + e, v);
+            load8(dx + ((b * F + f) * P + p) * lddx + e, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += v[i];
             if (f > 0 && p > 0 && dfeats) store8(dfeats + (((b * Tn + (f - 1)) * hw) + (p - 1)) * D + e, v);
@@ -108,21 +108,22 @@ __global__ __launch_bounds__(128) void tokens_bwd_kernel(const T* __restrict__ d
 }
 
 extern "C" int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos,
-                                void* x, int B, int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
-    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P) return ISTVT_ERR_SHAPE;
+                                void* x, long ldx, int B, int F, int P, int D, int pos_rows, int dtype,
+                                hipStream_t stream) {
+    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P || ldx < D || ldx % 8) return ISTVT_ERR_SHAPE;
     dim3 grid((unsigned)((long)B * F * P)), block(128);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tokens_fwd_kernel<T>), grid, block, 0, stream, (const T*)feats, space,
-                                             temporal, pos, (T*)x, B, F, P, D, pos_rows));
+                                             temporal, pos, (T*)x, B, F, P, D, pos_rows, ldx));
     return istvt_check_launch();
 }
 
 // dfeats may be null (features do not require grad).  dspace/dtemporal/dpos accumulate (fp32).
-extern "C" int istvt_tokens_bwd(const void* dx, void* dfeats, float* dspace, float* dtemporal, float* dpos, int B,
-                                int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
-    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P) return ISTVT_ERR_SHAPE;
+extern "C" int istvt_tokens_bwd(const void* dx, long lddx, void* dfeats, float* dspace, float* dtemporal, float* dpos,
+                                int B, int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
+    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P || lddx < D || lddx % 8) return ISTVT_ERR_SHAPE;
     dim3 grid(P, F), block(128);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tokens_bwd_kernel<T>), grid, block, 0, stream, (const T*)dx, (T*)dfeats,
-                                             dspace, dtemporal, dpos, B, F, P, D, pos_rows));
+                                             dspace, dtemporal, dpos, B, F, P, D, pos_rows, lddx));
     return istvt_check_launch();
 }
 
@@ -197,6 +198,40 @@ extern "C" int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype
         hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, stream, (const float*)in, (float*)out, n);
     else if (in_dtype == DT_BF16 && out_dtype == DT_BF16)
         hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, n);
+    else return ISTVT_ERR_DTYPE;
+    return istvt_check_launch();
+}
+
+// rows x cols cast between row-strided buffers (the bf16 GEMM operand copies of the fp32 weights get line-aligned rows)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast2d_kernel(const TI* __restrict__ in, long ldi, TO* __restrict__ out, long ldo,
+                                                     long rows, int cols) {
+    const int vpr = cols / 8;
+    const long nvec = rows * vpr;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const long m = i / vpr;
+        const int e = (int)(i % vpr) * 8;
+        float v[8];
+        load8(in + m * ldi + e, v);
+        store8(out + m * ldo + e, v);
+    }
+}
+
+extern "C" int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtype, long ldo, long rows,
+                            int cols, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || cols % 8 || ldi < cols || ldo < cols || ldi % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
+    long blocks = (rows * (cols / 8) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid((unsigned)blocks), block(256);
+    if (in_dtype == DT_F32 && out_dtype == DT_BF16)
+        hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)in, ldi, (bf16_t*)out, ldo, rows, cols);
+    else if (in_dtype == DT_BF16 && out_dtype == DT_F32)
+        hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)in, ldi, (float*)out, ldo, rows, cols);
+    else if (in_dtype == DT_F32 && out_dtype == DT_F32)
+        hipLaunchKernelGGL((cast2d_kernel<float, float>), grid, block, 0, stream, (const float*)in, ldi, (float*)out, ldo, rows, cols);
+    else if (in_dtype == DT_BF16 && out_dtype == DT_BF16)
+        hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, rows, cols);
     else return ISTVT_ERR_DTYPE;
     return istvt_check_launch();
 }

@@ -73,6 +73,7 @@ __device__ __forceinline__ float gelu_grad_fast(float u) {
 #include "gemm256r.h"
 #include "gemm256p.h"
 #include "gemm256q.h"
+#include "gemm256t.h"
 
 // Smallest output edge sent to the 256x256 DMA kernels.  Narrow outputs (the stem's 64/128-channel
 // pointwise convs over ~3 M pixels, K <= 288) waste MFMA lanes in a 256-wide tile, but those GEMMs
@@ -331,6 +332,11 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
             else if (residual) hipLaunchKernelGGL((gemm256p_kernel<0, true>), dim3(G), block, 0, stream, a);
             else hipLaunchKernelGGL((gemm256p_kernel<0, false>), dim3(G), block, 0, stream, a);
+        } else if (dbg == 0 && !a_kc && out_mode == 3 && !bias && !residual && epi == 0 && !a.flat_splits &&
+                   (long)K * lda * 2 < 0x7fffffffL && (long)K * ldb * 2 < 0x7fffffffL &&
+                   (getenv("ISTVT_GEMM_T") ? atoi(getenv("ISTVT_GEMM_T")) : 1)) {
+            // weight gradient: unit / ping-pong structure with transposing fragment reads (gemm256t.h)
+            hipLaunchKernelGGL(gemm256t_kernel, grid, block, 0, stream, a);
         } else if (dbg == 0 && ring >= 1 && a_kc) {
             if (a_kc) hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((gemm256r_kernel<true>), grid, block, 0, stream, a);

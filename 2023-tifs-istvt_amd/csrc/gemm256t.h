@@ -1,0 +1,203 @@
+// gemm256t: the weight-gradient ("TN") 256x256 bf16 GEMM on the unit / ping-pong structure of gemm256q.h.
+//
+//   C[m][n] (+ split z) = sum_{k in split z} A[k][m] * B[k][n]       A = dy [Ktok][M], B = x [Ktok][N], C fp32
+//
+// Both operands are ROW-contiguous in the reduction index (k = token), so a unit is [64 k][128 columns] (256-byte
+// rows, 16 KiB) and the MFMA fragments (8 consecutive k for one column) are read with ds_read_b64_tr_b16.
+// One workgroup = one (tile, reduction split); the splits write fp32 partial slabs that istvt_splitk_reduce sums.
+//
+//   unit stream per K tile kt (u = 4 kt + j):  AL (A columns 0..127), BL, BH, AH (A columns 128..255); slot u & 7
+//   DMA piece = 4 k-rows x 256 B; wave w stages k-rows 4w..4w+3 and 32+4w..32+4w+3 of every unit
+//   image: 16-byte chunk c of k-row k at position c ^ 2 f(k), f(k) = (k & 3) | ((k >> 3) & 1) << 2: the 32 lanes of
+//   one ds_read_b64_tr_b16 group read k-rows {k0..k0+3} and {k0+8..k0+11} at one column offset -> 8 distinct
+//   32-byte bank groups
+//   rows past the end of the reduction range / of the matrix are out of range for the whole-matrix descriptor and
+//   read as zeros; columns past M / N of the last tile read neighbouring (finite or not) data that only reaches
+//   output rows / columns which are never stored.
+// Phases, slots, stagger, hazards and vmcnt counts are those of gemm256q.h (two phases of 32 MFMA per K tile).
+#pragma once
+
+__device__ __forceinline__ int tswz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
+
+// fragment of 8 consecutive k (k0 .. k0+7) for column col16 + r out of a [64][128] unit image
+__device__ __forceinline__ bf16x8 t_frag(const char* img, int k0, int col16, int r) {
+    typedef short4v __attribute__((address_space(3))) * lds_ptr;
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const int q = r >> 2, pp = r & 3;
+    const int ka = k0 + q, kb = k0 + 4 + q;
+    const int chunk = (col16 >> 3) + (pp >> 1);
+    const char* pa = img + ka * 256 + ((chunk ^ tswz(ka)) << 4) + ((pp & 1) << 3);
+    const char* pb = img + kb * 256 + ((chunk ^ tswz(kb)) << 4) + ((pp & 1) << 3);
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pa));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(pb));
+    short8v s;
+    s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3]; s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, s);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lda = (int)p.lda, ldb = (int)p.ldb, ldc = (int)p.ldc;
+
+    const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + T256 - 1) / T256;
+    const int nwg = tiles_n * tiles_m;
+    int id = blockIdx.x;
+    {   // XCD-aware order (bijective): workgroups that share an XCD walk consecutive tiles
+        const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
+        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+    }
+    const int bm0 = (id / tiles_n) * T256, bn0 = (id % tiles_n) * T256;
+    const int k_begin = blockIdx.z * p.kper;
+    const int k_end = min(p.K, k_begin + p.kper);
+    const int nkt = (k_end - k_begin + 63) >> 6;
+    const int total_u = nkt * 4;
+
+    constexpr unsigned OOB = 0x80000000u, WINDOW = 0x7fffffffu, RSRC_FLAGS = 0x00020000u;
+    auto uni_ptr = [](const void* q) -> char* {
+        const unsigned long long u = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (char*)(((unsigned long long)hi << 32) | lo);
+    };
+    // ---- producer ------------------------------------------------------------------------------------
+    // piece i of a unit = k-rows i*32 + wave*4 + (lane >> 4), 16-byte chunk lane & 15 (swizzled on the source).
+    // The descriptors end at the split's last k-row: the reduction tail reads zeros.
+    unsigned va[2], vb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kr = i * 32 + wave * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ tswz(kr);
+        va[i] = (unsigned)(kr * lda * 2 + chunk * 16);
+        vb[i] = (unsigned)(kr * ldb * 2 + chunk * 16);
+    }
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.A), 0, k_end * lda * 2, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.B), 0, k_end * ldb * 2, RSRC_FLAGS);
+    int P = 0, p_s = 0;
+    auto issue_pair = [&](const int J0) {              // J0 = 0 -> (AL, BL), J0 = 2 -> (BH, AH) of K tile p_s
+        if (P >= total_u) return;
+        char* img = smem + (P & (QNU - 1)) * QU_BYTES + wave * 1024;
+        const int k0 = k_begin + p_s * 64;
+        const int sa = k0 * lda * 2 + (bm0 + (J0 == 2 ? 128 : 0)) * 2;
+        const int sb = k0 * ldb * 2 + (bn0 + (J0 == 2 ? 128 : 0)) * 2;
+        if (J0 == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + i * 8192), 16, va[i], sa, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, vb[i], sb, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + i * 8192), 16, vb[i], sb, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, va[i], sa, 0, 0);
+        }
+        P += 2;
+        if (J0 == 2) ++p_s;
+    };
+    issue_pair(0); issue_pair(2); issue_pair(0);           // units 0..5
+    wait_vm_n(min(6, 2 * max(0, total_u - 3)));            // units 0..2 landed (own pieces)
+    slot_barrier();
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b_unit = 1 + (wn >> 1);
+    int U0 = 0;
+
+    if (wm == 1) slot_barrier();               // stagger: waves 4..7 run one slot behind
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* ubase = smem + (kt & 1) * 4 * QU_BYTES;
+        const char* ua_lo = ubase;
+        const char* ua_hi = ubase + 3 * QU_BYTES;
+        const char* ub = ubase + b_unit * QU_BYTES;
+        bf16x8 af[4][2], bq[4][2];
+        auto mma = [&](const int mt0) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt0 + t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt0 + t][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto load_a = [&](const char* base) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) af[t][kh] = t_frag(base, kh * 32 + 8 * g, wm * 64 + t * 16, r);
+        };
+        // ---- phase A: AL x B
+        load_a(ua_lo);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) bq[t][kh] = t_frag(ub, kh * 32 + 8 * g, (wn & 1) * 64 + t * 16, r);
+        issue_pair(2);                                                   // units U0+6, U0+7
+        if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
+        slot_barrier();
+        mma(0);
+        slot_barrier();
+        // ---- phase B: AH x B
+        load_a(ua_hi);
+        issue_pair(0);                                                   // units U0+8, U0+9
+        if (total_u - 1 - (U0 + 6) >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 6)));
+        slot_barrier();
+        mma(4);
+        slot_barrier();
+        U0 += 4;
+    }
+    if (wm == 0) slot_barrier();               // re-align the two groups
+
+    // ---- epilogue: fp32 partial tile, wave-local 16-row passes through this wave's slab -----------------
+    float* slab = reinterpret_cast<float*>(smem + QNU * QU_BYTES + wave * PSLAB_BYTES);
+    const float alpha = p.alpha;
+    const int colc = (lane & 7) * 8, erow = lane >> 3;
+    const int row_w = wm * 64 + erow, col_w = wn * 64 + colc;
+    const bool n_ok = bn0 + col_w < p.N;                   // N % 8 == 0: a chunk of 8 columns is all in or all out
+    const int rows_left = p.M - bm0 - row_w;
+    const unsigned c_off = n_ok ? (unsigned)((row_w * ldc + col_w) * 4) : OOB;
+    const long c_org = ((long)blockIdx.z * p.slab + (long)bm0 * ldc + bn0) * 4;
+    const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr((char*)p.C + c_org), 0, WINDOW, RSRC_FLAGS);
+    const int re = lane & 15, ge = lane >> 4, l7 = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            *reinterpret_cast<f32x4*>(slab + re * 64 + (((nt * 4 + ge) ^ re) << 2)) = acc[pass][nt];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        u32x4 held[4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + erow;
+            const int rb = (pass >> 2) * 128 + (pass & 3) * 16 + it * 8;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7) ^ row) << 2));
+            f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7 + 1) ^ row) << 2));
+            lo *= alpha; hi *= alpha;
+            held[2 * it] = __builtin_bit_cast(u32x4, lo);
+            held[2 * it + 1] = __builtin_bit_cast(u32x4, hi);
+            const unsigned voff = rb < rows_left ? c_off : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(held[2 * it], c_rs, voff, rb * ldc * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(held[2 * it + 1], c_rs, voff + 16, rb * ldc * 4, 0);
+        }
+        // STORE-DATA HAZARD, see gemm256p.h: the data registers stay allocated and padded until the stores have read them
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1]), "+v"(held[2]), "+v"(held[3])::"memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    }
+}

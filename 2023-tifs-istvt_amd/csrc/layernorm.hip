@@ -55,7 +55,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     long M, int D, float eps) {
+                                                     long M, int D, float eps, long ldx, long ldy) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     ln_row_load<float>(beta, D, lane, bt);
     for (long m = wave; m < M; m += nwaves) {
         float v[LN_MAXCH][8];
-        ln_row_load<T>(x + m * D, D, lane, v);
+        ln_row_load<T>(x + m * ldx, D, lane, v);
         float mean, rstd;
         ln_stats(v, D, lane, eps, mean, rstd);
 #pragma unroll
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 float o[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = (v[c][i] - mean) * rstd * gm[c][i] + bt[c][i];
-                store8(y + m * D + e, o);
+                store8(y + m * ldy + e, o);
             }
         }
         if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
                                                           const float* __restrict__ beta, T* __restrict__ y,
                                                           T* __restrict__ diff, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, int Bn, int F, int P, int D,
-                                                          float eps) {
+                                                          float eps, long ldx, long ldy, long ldd) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * 4;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
         for (int f = 0; f < F; ++f) {
             const long m = (b * F + f) * P + pp;
             float v[LN_MAXCH][8];
-            ln_row_load<T>(x + m * D, D, lane, v);
+            ln_row_load<T>(x + m * ldx, D, lane, v);
             float mean, rstd;
             ln_stats(v, D, lane, eps, mean, rstd);
 #pragma unroll
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
                         dd[i] = (f >= 2) ? o[i] - prev[c][i] : o[i];
                         prev[c][i] = o[i];
                     }
-                    store8(y + m * D + e, o);
-                    store8(diff + m * D + e, dd);
+                    store8(y + m * ldy + e, o);
+                    store8(diff + m * ldd + e, dd);
                 }
             }
             if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
                                                      const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
-                                                     int D, int F, int P) {
+                                                     int D, int F, int P, long ld_dy, long ld_dy2, long ld_x, long ld_res,
+                                                     long ld_dx) {
     __shared__ float red[2][4][LN_MAXCH * 64 * 8];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const long wave = (long)blockIdx.x * 4 + wid;
@@ -184,14 +185,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
 #pragma unroll
         for (int c = 0; c < LN_MAXCH; ++c) {
             if (!on[c]) continue;
-            const long off = m * D + (lane + 64 * c) * 8;
-            raw_load(dy1 + off, r.dy[c]);
-            raw_load(x + off, r.x[c]);
+            const int e = (lane + 64 * c) * 8;
+            raw_load(dy1 + m * ld_dy + e, r.dy[c]);
+            raw_load(x + m * ld_x + e, r.x[c]);
             if (dy2) {
-                raw_load(dy2 + off, r.t0[c]);
-                if (r.sub) raw_load(dy2 + off + (long)P * D, r.t1[c]);
+                raw_load(dy2 + m * ld_dy2 + e, r.t0[c]);
+                if (r.sub) raw_load(dy2 + (m + P) * ld_dy2 + e, r.t1[c]);
             }
-            if (dres) raw_load(dres + off, r.rs[c]);
+            if (dres) raw_load(dres + m * ld_res + e, r.rs[c]);
         }
         r.mean = mean_in[m];
         r.rstd = rstd_in[m];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] += rr[i];
                 }
-                store8(dx + m * D + e, o);
+                store8(dx + m * ld_dx + e, o);
             }
         }
         if (more) cur = nxt;
@@ -280,34 +281,41 @@ static int ln_grid(long rows) {
     return (int)blocks;
 }
 
-extern "C" int istvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                   float* rstd, long M, int D, float eps, int dtype, hipStream_t stream) {
-    if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0) return ISTVT_ERR_SHAPE;
+// ld*: row strides in elements (>= D, multiples of 8): activations are kept with line-aligned rows (ops.py)
+extern "C" int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                   float* mean, float* rstd, long M, int D, float eps, int dtype, hipStream_t stream) {
+    if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0 || ldx < D || ldy < D || ldx % 8 || ldy % 8) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x,
-                                             gamma, beta, (T*)y, mean, rstd, M, D, eps));
+                                             gamma, beta, (T*)y, mean, rstd, M, D, eps, ldx, ldy));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_layernorm_fwd_diff(const void* x, const float* gamma, const float* beta, void* y, void* diff,
-                                        float* mean, float* rstd, int B, int F, int P, int D, float eps, int dtype,
-                                        hipStream_t stream) {
+extern "C" int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                        void* diff, long ldd, float* mean, float* rstd, int B, int F, int P, int D,
+                                        float eps, int dtype, hipStream_t stream) {
     if (D % 8 != 0 || D > LN_MAXCH * 512 || B <= 0 || F <= 0 || P <= 0) return ISTVT_ERR_SHAPE;
+    if (ldx < D || ldy < D || ldd < D || ldx % 8 || ldy % 8 || ldd % 8) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_diff_kernel<T>), dim3(ln_grid((long)B * P)), dim3(256), 0, stream,
-                                             (const T*)x, gamma, beta, (T*)y, (T*)diff, mean, rstd, B, F, P, D, eps));
+                                             (const T*)x, gamma, beta, (T*)y, (T*)diff, mean, rstd, B, F, P, D, eps, ldx,
+                                             ldy, ldd));
     return istvt_check_launch();
 }
 
 // dy2 == null: plain LayerNorm backward (F, P ignored).  dres may be null.  dgamma/dbeta accumulate.
-extern "C" int istvt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* mean,
-                                   const float* rstd, const float* gamma, const void* dres, void* dx, float* dgamma,
-                                   float* dbeta, long M, int D, int F, int P, int dtype, hipStream_t stream) {
+extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, long ld_dy2, const void* x, long ld_x,
+                                   const float* mean, const float* rstd, const float* gamma, const void* dres,
+                                   long ld_res, void* dx, long ld_dx, float* dgamma, float* dbeta, long M, int D, int F,
+                                   int P, int dtype, hipStream_t stream) {
     if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0) return ISTVT_ERR_SHAPE;
+    if (ld_dy < D || ld_x < D || ld_dx < D || ld_dy % 8 || ld_x % 8 || ld_dx % 8) return ISTVT_ERR_SHAPE;
+    if ((dy2 && (ld_dy2 < D || ld_dy2 % 8)) || (dres && (ld_res < D || ld_res % 8))) return ISTVT_ERR_SHAPE;
     if (dy2 && (F <= 0 || P <= 0 || M % ((long)F * P) != 0)) return ISTVT_ERR_SHAPE;
     if (!dy2) { F = 1; P = 1; }
     long blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, stream,
                                              (const T*)dy, (const T*)dy2, (const T*)x, mean, rstd, gamma,
-                                             (const T*)dres, (T*)dx, dgamma, dbeta, M, D, F, P));
+                                             (const T*)dres, (T*)dx, dgamma, dbeta, M, D, F, P, ld_dy, ld_dy2, ld_x,
+                                             ld_res, ld_dx));
     return istvt_check_launch();
 }

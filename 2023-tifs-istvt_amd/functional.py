@@ -29,43 +29,51 @@ def _target(p):
 
 
 class LayerNormFn(Function):
-    """nn.LayerNorm over the last dim (reference module.py:15-21)."""
+    """nn.LayerNorm over the last dim (reference module.py:15-21).  fork=True also returns the input itself: a
+    caller that uses x both as the LayerNorm input and as a residual takes the second output for the residual, and
+    the gradient arriving through it is added inside the LayerNorm backward kernel (no separate add pass)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
-        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+    def forward(ctx, x, gamma, beta, eps, fork=False):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, pad=True)
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
+        if dy is None:                       # only the pass-through output was used
+            return dres, None, None, None, None
         dg, rg = _target(gamma)
         db, rb = _target(beta)
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db)
-        return dx, rg, rb, None
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True)
+        return dx, rg, rb, None, None
 
 
 class LayerNormDiffFn(Function):
-    """LayerNorm that also returns the frame difference of its output (module.py:193)."""
+    """LayerNorm that also returns the frame difference of its output (module.py:193); fork as in LayerNormFn."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, B, F, P):
-        y, diff, mean, rstd = ops.layernorm_fwd_diff(x, gamma, beta, eps, B, F, P)
+    def forward(ctx, x, gamma, beta, eps, B, F, P, fork=False):
+        y, diff, mean, rstd = ops.layernorm_fwd_diff(x, gamma, beta, eps, B, F, P, pad=True)
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.geom = (F, P)
-        return y, diff
+        ctx.set_materialize_grads(False)
+        return (y, diff, x.view_as(x)) if fork else (y, diff)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy, ddiff):
+    def backward(ctx, dy, ddiff, dres=None):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         F, P = ctx.geom
         dg, rg = _target(gamma)
         db, rb = _target(beta)
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, F=F, P=P)
-        return dx, rg, rb, None, None, None, None
+        if dy is None:
+            dy = torch.zeros_like(ddiff if ddiff is not None else x)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, dres=dres, F=F, P=P, pad=True)
+        return dx, rg, rb, None, None, None, None, None
 
 
 class FrameDiffFn(Function):
@@ -101,8 +109,8 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
-        w = ops.weight_as(weight, x.dtype)
-        y = ops.linear_fwd(x, w, bias, residual)
+        w = ops.weight_as(weight, x.dtype, pad=True)
+        y = ops.linear_fwd(x, w, bias, residual, pad=True)
         ctx.save_for_backward(x, weight, bias)
         ctx.has_res = residual is not None
         return y
@@ -111,9 +119,8 @@ class LinearFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        dy = dy.contiguous()
         w = ops.weight_as(weight, dy.dtype)
-        dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dx = ops.linear_dgrad(dy, w, pad=True) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dy, x, weight) if ctx.needs_input_grad[1] else None
         db = _bgrad(dy, bias) if (bias is not None and ctx.needs_input_grad[2]) else None
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
@@ -125,8 +132,8 @@ class FeedForwardFn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual):
-        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype), b1, gelu=True)
-        y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype), b2, residual)
+        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True)
+        y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype, pad=True), b2, residual, pad=True)
         ctx.save_for_backward(x, u, g, w1, b1, w2, b2)
         ctx.has_res = residual is not None
         return y
@@ -135,11 +142,10 @@ class FeedForwardFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, u, g, w1, b1, w2, b2 = ctx.saved_tensors
-        dy = dy.contiguous()
-        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype), gelu_u=u)       # (dy W2) * gelu'(u)
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype), gelu_u=u, pad=True)       # (dy W2) * gelu'(u)
         dw2 = _wgrad(dy, g, w2)
         db2 = _bgrad(dy, b2)
-        dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype)) if ctx.needs_input_grad[0] else None
+        dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype), pad=True) if ctx.needs_input_grad[0] else None
         dw1 = _wgrad(du, x, w1)
         db1 = _bgrad(du, b1)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
@@ -185,7 +191,7 @@ class TokensFn(Function):
 
     @staticmethod
     def forward(ctx, feats, space, temporal, pos):
-        x = ops.tokens_fwd(feats, space, temporal, pos)
+        x = ops.tokens_fwd(feats, space, temporal, pos, pad=True)
         ctx.save_for_backward(space, temporal, pos)
         ctx.geom = tuple(feats.shape)
         return x
@@ -200,8 +206,26 @@ class TokensFn(Function):
         return dfeats, rs, rt, rp
 
 
-def layer_norm(x, gamma, beta, eps=1e-5):
-    return LayerNormFn.apply(x, gamma, beta, eps)
+class TakeClsFn(Function):
+    """x[:, 0, 0] of x viewed as (B, F, P, D): the temporal-token frame's space-token slot (vivit.py:144-146).  The
+    backward writes the B rows into a zeroed buffer that keeps the line-aligned row layout."""
+
+    @staticmethod
+    def forward(ctx, x, B, F, P):
+        ctx.geom = (B, F, P, x.shape[-1], x.dtype)
+        return x.reshape(B, F, P, -1)[:, 0, 0].contiguous()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, F, P, D, dtype = ctx.geom
+        dx = ops.zeros_rows(B * F * P, D, dtype, g.device)
+        dx.view(B, F, P, D)[:, 0, 0] = g
+        return dx.view(B, F * P, D), None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, fork=False):
+    return LayerNormFn.apply(x, gamma, beta, eps, fork)
 
 
 def linear(x: Tensor, weight: Tensor, bias=None, residual=None) -> Tensor:

@@ -36,9 +36,24 @@ class PreNorm(nn.Module):
         self.fn = fn
 
     def forward(self, x, **kwargs):
+        # Two extensions for STTransformer (both default off, the reference semantics are unchanged):
+        #   fork=True        -> returns (fn(norm(x)), x'): x' is x routed through the LayerNorm's autograd node, so
+        #                       a caller that adds x as a residual LATER gets that gradient summed inside the
+        #                       LayerNorm backward kernel instead of a separate add pass;
+        #   residual='input' -> fn(norm(x), residual=x) with the same routing.
+        fork = kwargs.pop('fork', False)
+        own_res = isinstance(kwargs.get('residual'), str) and kwargs['residual'] == 'input'
         fused = getattr(self.fn, 'forward_prenorm', None)
         if fused is not None:           # temporal attention: LayerNorm + frame difference in one kernel
-            return fused(x, self.norm, **kwargs)
+            if own_res:
+                raise NotImplementedError("residual='input' is not used with the temporal attention block")
+            return fused(x, self.norm, fork=fork, **kwargs)
+        if fork or own_res:
+            y, xr = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, fork=True)
+            if own_res:
+                kwargs['residual'] = xr
+            out = self.fn(y, **kwargs)
+            return (out, xr) if fork else out
         return self.fn(Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
 
 
@@ -133,10 +148,11 @@ class TemporalResidualAttention(nn.Module):
         diff = Fn.FrameDiffFn.apply(x2, b, frames, hw)
         return self._attend(x2, diff, b, n, hw, frames, residual)
 
-    def forward_prenorm(self, x, norm, hw=None, residual=None):
+    def forward_prenorm(self, x, norm, hw=None, residual=None, fork=False):
         """PreNorm(self)(x): LayerNorm and the frame difference come out of one kernel."""
         b, n, d = x.shape
         hw = self.hw if hw is None else hw
         frames = _frames(n, hw, 'TemporalResidualAttention')
-        xn, diff = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw)
-        return self._attend(xn, diff, b, n, hw, frames, residual)
+        outs = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw, fork)
+        y = self._attend(outs[0], outs[1], b, n, hw, frames, residual)
+        return (y, outs[2].view(b, n, d)) if fork else y

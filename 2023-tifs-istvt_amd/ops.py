@@ -45,6 +45,42 @@ def _stream() -> int:
 
 
 # ------------------------------------------------------------------------------------------
+# Row-strided activations.  The GEMMs stage their operands with LDS-DMA, which is priced per cache
+# line touched: a [M][728] bf16 tensor has 1456-byte rows, so every 128-byte piece of a row straddles
+# two lines.  Transformer activations (and the bf16 operand copies of the weights) are therefore
+# allocated with rows padded to a multiple of 64 elements and handed around as [M, D] VIEWS of the
+# [M, ld] buffer; every kernel takes the row stride.  Pad columns are never read and never written.
+ROW_ALIGN = 64
+
+
+def pad_ld(n: int) -> int:
+    return (n + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+
+
+def empty_rows(M: int, D: int, dtype, device, pad: bool = True) -> Tensor:
+    ld = pad_ld(D) if pad else D
+    buf = torch.empty((M, ld), dtype=dtype, device=device)
+    return buf if ld == D else buf[:, :D]
+
+
+def zeros_rows(M: int, D: int, dtype, device, pad: bool = True) -> Tensor:
+    ld = pad_ld(D) if pad else D
+    buf = torch.zeros((M, ld), dtype=dtype, device=device)
+    return buf if ld == D else buf[:, :D]
+
+
+def rows(t: Tensor) -> Tuple[Tensor, int]:
+    """(2-D view [M, D] with unit column stride, row stride in elements); copies only if the layout is not that."""
+    t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1])
+    M, D = t2.shape
+    if M == 1:
+        return (t2 if t2.stride(1) == 1 else t2.contiguous()), D
+    if t2.stride(1) != 1 or t2.stride(0) < D or t2.stride(0) % 8 != 0 or t2.data_ptr() % 16 != 0:
+        t2 = t2.contiguous()
+    return t2, t2.stride(0)
+
+
+# ------------------------------------------------------------------------------------------
 # fp32 master weight -> compute-dtype operand, cached per parameter version
 _wcache: dict = {}
 G256_MIN = 64          # smallest output edge routed to the 256x256 DMA GEMM (mirrors ISTVT_G256_MIN in gemm.hip)
@@ -62,19 +98,27 @@ def cast(t: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
-def weight_as(w: Tensor, dtype: torch.dtype) -> Tensor:
-    """Contiguous 2-D view of a (fp32) parameter in the compute dtype; bf16 copies are cached
-    until the parameter is modified in place (optimizer step bumps ``_version``)."""
+def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
+    """2-D view of a (fp32) parameter in the compute dtype; bf16 copies are cached until the parameter is modified
+    in place (optimizer step bumps ``_version``).  pad=True: the copy has line-aligned rows (a [N, K] view of a
+    [N, pad_ld(K)] buffer), the layout the DMA-staged GEMMs want for their B operand."""
     w2 = w.detach()
     if w2.dim() != 2:
         w2 = w2.reshape(w2.shape[0], -1)
     if w2.dtype == dtype:
         return _c(w2)
-    key = id(w)                       # id-keyed: Tensor.__eq__ is elementwise, so tensors cannot be dict keys
+    pad = pad and w2.shape[1] % 8 == 0 and pad_ld(w2.shape[1]) != w2.shape[1]
+    key = (id(w), 'p') if pad else id(w)    # id-keyed: Tensor.__eq__ is elementwise, so tensors cannot be dict keys
     hit = _wcache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].dtype == dtype:
         return hit[2]
-    out = cast(w2, dtype)
+    if pad:
+        w2 = _c(w2)
+        out = empty_rows(w2.shape[0], w2.shape[1], dtype, w2.device)
+        _lib.check(_lib.lib().istvt_cast2d(w2.data_ptr(), dtype_code(w2), w2.shape[1], out.data_ptr(), _DT[dtype],
+                                           out.stride(0), w2.shape[0], w2.shape[1], _stream()), 'istvt_cast2d')
+    else:
+        out = cast(w2, dtype)
     _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)
     return out
 
@@ -129,21 +173,25 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               gelu: bool = False):
-    """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype)."""
+               gelu: bool = False, pad: bool = False):
+    """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype); both may
+    be row-strided views.  pad=True: the outputs are [M, N] views with line-aligned rows."""
     M, K = x.shape
     N = w.shape[0]
     if w.shape[1] != K:
         raise RuntimeError('linear: weight %s does not match input width %d' % (tuple(w.shape), K))
-    x = _c(x)
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    x, lda = rows(x)
+    w, ldb = rows(w)
+    y = empty_rows(M, N, x.dtype, x.device, pad)
+    ldc = y.stride(0) if M > 1 else N
     if gelu:
-        g = torch.empty_like(y)
-        gemm_raw(x, K, True, w, K, True, y, N, M, N, K, bias=bias, C2=g, epi=1)
+        g = empty_rows(M, N, x.dtype, x.device, pad)
+        gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, C2=g, epi=1)
         return y, g
+    ldr = 0
     if residual is not None:
-        residual = _c(residual)
-    gemm_raw(x, K, True, w, K, True, y, N, M, N, K, bias=bias, residual=residual, ldr=N)
+        residual, ldr = rows(residual)
+    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr)
     return y
 
 
@@ -156,7 +204,9 @@ def weight_t_as(w: Tensor, dtype: torch.dtype) -> Tensor:
     hit = _wcache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].dtype == dtype:
         return hit[2]
-    out = weight_as(w, dtype).t().contiguous()
+    wt = weight_as(w, dtype).t()
+    out = empty_rows(wt.shape[0], wt.shape[1], dtype, w.device)
+    out.copy_(wt)
     _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)
     return out
 
@@ -168,26 +218,36 @@ def _transposed_operand(w: Tensor) -> Tensor:
     hit = _wcache.get(key)
     if hit is not None and hit[0]() is w:
         return hit[2]
-    wt = w.t().contiguous()
+    wt = empty_rows(w.shape[1], w.shape[0], w.dtype, w.device)        # line-aligned rows for the DMA-staged GEMM
+    wt.copy_(w.t())
     _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), 0, wt)
     return wt
 
 
-def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Optional[Tensor] = None) -> Tensor:
+def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Optional[Tensor] = None,
+                 pad: bool = False) -> Tensor:
     """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u).
     wt = w^T [K,N] (optional): use the k-contiguous kernel instead of the transposed-operand one."""
     M, N = dy.shape
     K = w.shape[1]
-    dy = _c(dy)
-    dx = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    dy, lda = rows(dy)
+    dx = empty_rows(M, K, dy.dtype, dy.device, pad)
+    ldc = dx.stride(0) if M > 1 else K
     epi = 2 if gelu_u is not None else 0
-    c2 = _c(gelu_u) if gelu_u is not None else None
+    c2 = None
+    if gelu_u is not None:
+        c2, ld2 = rows(gelu_u)
+        if ld2 != ldc:                    # the kernel reads C2 with C's row stride
+            c2 = empty_rows(M, K, dy.dtype, dy.device, pad)
+            c2.copy_(gelu_u)
     if wt is None and dy.dtype == torch.bfloat16 and M >= G256_MIN and K >= G256_MIN and N % 8 == 0:
         wt = _transposed_operand(w)
     if wt is not None:
-        gemm_raw(dy, N, True, wt, N, True, dx, K, M, K, N, C2=c2, epi=epi)
+        wt, ldb = rows(wt)
+        gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi)
     else:
-        gemm_raw(dy, N, True, w, K, False, dx, K, M, K, N, C2=c2, epi=epi)
+        w, ldb = rows(w)
+        gemm_raw(dy, lda, True, w, ldb, False, dx, ldc, M, K, N, C2=c2, epi=epi)
     return dx
 
 
@@ -206,7 +266,7 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """out[N,K] (+)= dy.T @ x   (dy [M,N], x [M,K]); fp32 accumulate via split-K atomics."""
     M, N = dy.shape
     K = x.shape[1]
-    dy, x = _c(dy), _c(x)
+    (dy, ldy), (x, ldx) = rows(dy), rows(x)
     if out is None:
         out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
     big = dy.dtype == torch.bfloat16 and N >= G256_MIN and K >= G256_MIN and N % 8 == 0 and K % 8 == 0
@@ -218,22 +278,23 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         kper = -(-(-(-M // splits)) // 64) * 64          # what the C side derives: ceil(ceil(M/s)/64)*64
         splits = -(-M // kper)
         ws = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
-        gemm_raw(dy, N, False, x, K, False, ws, K, N, K, M, out_mode=3, splitk=splits)
+        gemm_raw(dy, ldy, False, x, ldx, False, ws, K, N, K, M, out_mode=3, splitk=splits)
         _lib.check(_lib.lib().istvt_splitk_reduce(ws.data_ptr(), splits, N * K, out.data_ptr(), _stream()),
                    'istvt_splitk_reduce')
     else:
-        gemm_raw(dy, N, False, x, K, False, out, K, N, K, M, out_mode=2, splitk=splits)
+        gemm_raw(dy, ldy, False, x, ldx, False, out, K, N, K, M, out_mode=2, splitk=splits)
     return out
 
 
 def colsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     M, N = x.shape
-    x = _c(_req(x))
+    x, ld = rows(_req(x))
     if out is None:
         out = torch.zeros((N,), dtype=torch.float32, device=x.device)
     if N % 8 == 0:
-        _lib.check(_lib.lib().istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, N, dtype_code(x), _stream()), 'istvt_colsum')
+        _lib.check(_lib.lib().istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, ld, dtype_code(x), _stream()), 'istvt_colsum')
     else:
+        x = _c(x)
         # narrow outputs (e.g. the 1-logit head): a [N][1] GEMM against ones keeps it on the HIP path
         ones = torch.ones((M, 8), dtype=x.dtype, device=x.device)
         tmp = torch.zeros((N, 8), dtype=torch.float32, device=x.device)
@@ -243,50 +304,52 @@ def colsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------
-def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float):
-    x = _c(_req(x))
-    D = x.shape[-1]
-    M = x.numel() // D
-    y = torch.empty_like(x)
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, pad: bool = False):
+    """x [..., D] (row-strided views allowed) -> y [M, D] (pad=True: line-aligned rows), mean [M], rstd [M]."""
+    x2, ldx = rows(_req(x))
+    M, D = x2.shape
+    y = empty_rows(M, D, x.dtype, x.device, pad)
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _lib.check(_lib.lib().istvt_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                              mean.data_ptr(), rstd.data_ptr(), M, D, eps, dtype_code(x), _stream()),
-               'istvt_layernorm_fwd')
-    return y, mean, rstd
+    _lib.check(_lib.lib().istvt_layernorm_fwd(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                              y.stride(0) if M > 1 else D, mean.data_ptr(), rstd.data_ptr(), M, D, eps,
+                                              dtype_code(x), _stream()), 'istvt_layernorm_fwd')
+    return (y if x.dim() == 2 else y.view(*x.shape)), mean, rstd
 
 
-def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: int, F: int, P: int):
-    x = _c(_req(x))
-    D = x.shape[-1]
-    if x.numel() != B * F * P * D:
+def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: int, F: int, P: int, pad: bool = False):
+    x2, ldx = rows(_req(x))
+    M, D = x2.shape
+    if M != B * F * P:
         raise RuntimeError('layernorm_fwd_diff: %s is not (B=%d, F*P=%d*%d, D)' % (tuple(x.shape), B, F, P))
-    y = torch.empty_like(x)
-    diff = torch.empty_like(x)
-    M = B * F * P
+    y = empty_rows(M, D, x.dtype, x.device, pad)
+    diff = empty_rows(M, D, x.dtype, x.device, pad)
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                                   diff.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, F, P, D, eps,
-                                                   dtype_code(x), _stream()), 'istvt_layernorm_fwd_diff')
+    _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                   y.stride(0), diff.data_ptr(), diff.stride(0), mean.data_ptr(),
+                                                   rstd.data_ptr(), B, F, P, D, eps, dtype_code(x), _stream()),
+               'istvt_layernorm_fwd_diff')
     return y, diff, mean, rstd
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
-                  dy2: Optional[Tensor] = None, dres: Optional[Tensor] = None, F: int = 1, P: int = 1) -> Tensor:
-    dy = _c(_req(dy))
-    D = x.shape[-1]
-    M = x.numel() // D
-    dx = torch.empty_like(x)
+                  dy2: Optional[Tensor] = None, dres: Optional[Tensor] = None, F: int = 1, P: int = 1,
+                  pad: bool = False) -> Tensor:
+    x2, ldx = rows(x)
+    M, D = x2.shape
+    dy, ld_dy = rows(_req(dy))
+    ld_dy2 = ld_res = 0
     if dy2 is not None:
-        dy2 = _c(dy2)
+        dy2, ld_dy2 = rows(dy2)
     if dres is not None:
-        dres = _c(dres)
-    _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), _ptr(dy2), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                              gamma.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
-                                              dbeta.data_ptr(), M, D, F, P, dtype_code(x), _stream()),
-               'istvt_layernorm_bwd')
-    return dx
+        dres, ld_res = rows(dres)
+    dx = empty_rows(M, D, x.dtype, x.device, pad)
+    _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), ld_dy, _ptr(dy2), ld_dy2, x2.data_ptr(), ldx, mean.data_ptr(),
+                                              rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(),
+                                              dx.stride(0) if M > 1 else D, dgamma.data_ptr(), dbeta.data_ptr(), M, D, F,
+                                              P, dtype_code(x), _stream()), 'istvt_layernorm_bwd')
+    return dx if x.dim() == 2 else dx.view(*x.shape)
 
 
 # ------------------------------------------------------------------------------------------
@@ -337,7 +400,7 @@ def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: in
 
 
 # ------------------------------------------------------------------------------------------
-def tokens_fwd(feats: Tensor, space: Tensor, temporal: Tensor, pos: Tensor) -> Tensor:
+def tokens_fwd(feats: Tensor, space: Tensor, temporal: Tensor, pos: Tensor, pad: bool = False) -> Tensor:
     """feats [B,T,hw,D] -> x [B,(T+1)*(hw+1),D]; pos is the full (1,T,P_decl,D) parameter."""
     feats = _c(_req(feats))
     B, T, hw, D = feats.shape
@@ -347,19 +410,19 @@ def tokens_fwd(feats: Tensor, space: Tensor, temporal: Tensor, pos: Tensor) -> T
                            % (T, pos.shape[1]))          # same failure the reference hits at vivit.py:138
     if pos.shape[2] < P:
         raise RuntimeError('pos_embedding has %d tokens per frame, input needs %d' % (pos.shape[2], P))
-    x = torch.empty((B, F * P, D), dtype=feats.dtype, device=feats.device)
+    x = empty_rows(B * F * P, D, feats.dtype, feats.device, pad)
     _lib.check(_lib.lib().istvt_tokens_fwd(feats.data_ptr(), space.data_ptr(), temporal.data_ptr(), pos.data_ptr(),
-                                           x.data_ptr(), B, F, P, D, pos.shape[2], dtype_code(feats), _stream()),
-               'istvt_tokens_fwd')
-    return x
+                                           x.data_ptr(), x.stride(0), B, F, P, D, pos.shape[2], dtype_code(feats),
+                                           _stream()), 'istvt_tokens_fwd')
+    return x.view(B, F * P, D)
 
 
 def tokens_bwd(dx: Tensor, B: int, T: int, hw: int, D: int, dspace: Tensor, dtemporal: Tensor, dpos: Tensor,
                need_dfeats: bool) -> Optional[Tensor]:
-    dx = _c(_req(dx))
+    dx, lddx = rows(_req(dx))
     F, P = T + 1, hw + 1
     dfeats = torch.empty((B, T, hw, D), dtype=dx.dtype, device=dx.device) if need_dfeats else None
-    _lib.check(_lib.lib().istvt_tokens_bwd(dx.data_ptr(), _ptr(dfeats), dspace.data_ptr(), dtemporal.data_ptr(),
+    _lib.check(_lib.lib().istvt_tokens_bwd(dx.data_ptr(), lddx, _ptr(dfeats), dspace.data_ptr(), dtemporal.data_ptr(),
                                            dpos.data_ptr(), B, F, P, D, dpos.shape[2], dtype_code(dx), _stream()),
                'istvt_tokens_bwd')
     return dfeats

@@ -19,6 +19,11 @@
  *     (they are the .grad buffers).
  *   - row-major everywhere; activations of the transformer are [M = B*F*P][D] with rows
  *     ordered (clip b, frame f, token p); stem activations are NHWC [frames][H][W][C].
+ *   - `ld*` arguments are row strides in ELEMENTS (>= the row width, multiples of 8).  The host
+ *     keeps transformer activations and the bf16 GEMM operand copies of the weights with rows
+ *     padded to a multiple of 64 elements (728 -> 768, 2912 -> 2944) so that every row starts on
+ *     a 128-byte line: the LDS-DMA staging of the GEMMs is priced per cache line touched
+ *     (tools/dma_probe.hip).  Pad columns are never read as data and never written.
  */
 #ifndef ISTVT_HIP_H
 #define ISTVT_HIP_H
@@ -51,16 +56,18 @@ int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b
 int istvt_splitk_reduce(const float* ws, int splits, long n, float* out, istvt_stream_t stream);
 
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
-int istvt_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                        long M, int D, float eps, int dtype, istvt_stream_t stream);
+int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,
+                        float* rstd, long M, int D, float eps, int dtype, istvt_stream_t stream);
 /* also writes diff = frame difference of y (module.py:193): rows (b,f,p), diff[f] = y[f] - y[f-1] for f >= 2 */
-int istvt_layernorm_fwd_diff(const void* x, const float* gamma, const float* beta, void* y, void* diff, float* mean,
-                             float* rstd, int B, int F, int P, int D, float eps, int dtype, istvt_stream_t stream);
+int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                             void* diff, long ldd, float* mean, float* rstd, int B, int F, int P, int D, float eps,
+                             int dtype, istvt_stream_t stream);
 /* dy2 (may be NULL) = gradient w.r.t. diff; dres (may be NULL) = gradient arriving through the
  * residual connection, added to dx.  dgamma/dbeta accumulate. */
-int istvt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* mean, const float* rstd,
-                        const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta, long M, int D,
-                        int F, int P, int dtype, istvt_stream_t stream);
+int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, long ld_dy2, const void* x, long ld_x,
+                        const float* mean, const float* rstd, const float* gamma, const void* dres, long ld_res,
+                        void* dx, long ld_dx, float* dgamma, float* dbeta, long M, int D, int F, int P, int dtype,
+                        istvt_stream_t stream);
 
 /* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
  * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)'), out [BF*P][heads*dh],
@@ -79,10 +86,10 @@ int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, voi
                             int heads, int dh, float scale, int dtype, istvt_stream_t stream);
 
 /* ---- token assembly (DSTTr.forward, vivit.py:133-142) -------------------------------------- */
-int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, int B,
-                     int F, int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
-int istvt_tokens_bwd(const void* dx, void* dfeats, float* dspace, float* dtemporal, float* dpos, int B, int F, int P,
-                     int D, int pos_rows, int dtype, istvt_stream_t stream);
+int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, long ldx,
+                     int B, int F, int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
+int istvt_tokens_bwd(const void* dx, long lddx, void* dfeats, float* dspace, float* dtemporal, float* dpos, int B, int F,
+                     int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
 
 /* frame difference of module.py:193 (adjoint = 1: its transpose, for the backward) */
 int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int adjoint, int dtype,
@@ -150,6 +157,9 @@ int istvt_subsample2(const void* in, void* out, int frames, int H, int W, int C,
 /* out[n] += sum_m x[m][n]  (bias gradients) */
 int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, istvt_stream_t stream);
 int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, istvt_stream_t stream);
+/* rows x cols cast between row-strided buffers (bf16 operand copies of fp32 weights with line-aligned rows) */
+int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtype, long ldo, long rows, int cols,
+                 istvt_stream_t stream);
 
 #ifdef __cplusplus
 }

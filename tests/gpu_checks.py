@@ -36,6 +36,36 @@ def ints(shape, dtype, seed, lo=-2, hi=3):
     return torch.randint(lo, hi, shape, generator=g).to(DEV).to(dtype)
 
 
+def padded(t):
+    """the same values as a [M, D] view of a buffer with line-aligned rows (ops.empty_rows), pad columns = NaN: a
+    kernel that reads a pad column as data, or assumes stride == width, fails the check"""
+    M, D = t.shape
+    buf = torch.full((M, ops.pad_ld(D) + 64), float('nan'), dtype=t.dtype, device=t.device)
+    v = buf[:, :D]
+    v.copy_(t)
+    return v
+
+
+def gemm_padded(dtype, M=515, N=728, K=1544):
+    """row-strided operands and outputs (the transformer's activation layout): forward with bias + residual, GELU
+    pair, both input gradients, weight gradient.  Integer data -> exact."""
+    x, w, r = ints((M, K), dtype, 1), ints((N, K), dtype, 2), ints((M, N), dtype, 3)
+    b = ints((N,), torch.float32, 4)
+    xp, wp, rp = padded(x), padded(w), padded(r)
+    ref = x.double() @ w.double().t() + b.double() + r.double()
+    y = ops.linear_fwd(xp, wp, b, rp, pad=True)
+    assert y.stride(0) == ops.pad_ld(N)
+    e = float((y.double() - ref.to(dtype).double()).abs().max())
+    dy = ints((M, N), dtype, 5, -1, 2)
+    dx = ops.linear_dgrad(padded(dy), w, pad=True)
+    e = max(e, float((dx.double() - (dy.double() @ w.double()).to(dtype).double()).abs().max()))
+    dw = ops.linear_wgrad(padded(dy), xp)
+    e = max(e, float((dw.double() - dy.double().t() @ x.double()).abs().max()))
+    u, g = ops.linear_fwd(xp, wp, None, gelu=True, pad=True)
+    e = max(e, float((u.double() - (x.double() @ w.double().t()).to(dtype).double()).abs().max()))
+    return e, 0.0
+
+
 # ------------------------------------------------------------------------------------------ GEMM
 def gemm_exact(dtype, mode, M=200, N=136, K=104):
     """integer data -> exact; mode in fwd/dgrad/wgrad; covers M/N/K tails."""
@@ -92,16 +122,20 @@ def gemm_real(dtype, mode):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
-def layernorm(dtype, D=728, M=1003):
+def layernorm(dtype, D=728, M=1003, pad=False):
     x, g, b = rnd((M, D), dtype, 1, 2.0), rnd((D,), torch.float32, 2, 0.2) + 1, rnd((D,), torch.float32, 3, 0.1)
-    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
+    if pad:
+        x = padded(x)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5, pad=pad)
     xd = x.double().requires_grad_(True)
     gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5)
     dy, dres = rnd((M, D), dtype, 4), rnd((M, D), dtype, 5)
     ref.backward(dy.double())
     dg, db = torch.zeros_like(g), torch.zeros_like(b)
-    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres)
+    if pad:
+        dres = padded(dres)                 # dy stays contiguous: the strides are independent
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres, pad=pad)
     e = max(relerr(y, ref), relerr(dx, xd.grad + dres.double()), relerr(dg, gd.grad), relerr(db, bd.grad))
     return e, TOL[dtype]
 
@@ -111,10 +145,12 @@ def _diff_ref(y, B, F, P):
     return torch.cat((yr[:, :2], yr[:, 2:] - yr[:, 1:-1]), dim=1).reshape(B * F * P, -1)
 
 
-def layernorm_diff(dtype, B=2, F=9, P=37, D=728):
+def layernorm_diff(dtype, B=2, F=9, P=37, D=728, pad=False):
     M = B * F * P
     x, g, b = rnd((M, D), dtype, 1, 2.0), rnd((D,), torch.float32, 2, 0.2) + 1, rnd((D,), torch.float32, 3, 0.1)
-    y, diff, mean, rstd = ops.layernorm_fwd_diff(x, g, b, 1e-5, B, F, P)
+    if pad:
+        x = padded(x)
+    y, diff, mean, rstd = ops.layernorm_fwd_diff(x, g, b, 1e-5, B, F, P, pad=pad)
     xd = x.double().requires_grad_(True)
     gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
     ry = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5)
@@ -122,7 +158,9 @@ def layernorm_diff(dtype, B=2, F=9, P=37, D=728):
     dy, dd = rnd((M, D), dtype, 4), rnd((M, D), dtype, 5)
     (ry * dy.double()).sum().add((rdiff * dd.double()).sum()).backward()
     dg, db = torch.zeros_like(g), torch.zeros_like(b)
-    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dy2=dd, F=F, P=P)
+    if pad:
+        dy, dd = padded(dy), padded(dd)
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dy2=dd, F=F, P=P, pad=pad)
     e = max(relerr(y, ry), relerr(diff, rdiff), relerr(dx, xd.grad), relerr(dg, gd.grad), relerr(db, bd.grad))
     return e, TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
 
@@ -177,11 +215,11 @@ def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64):
 
 
 # ------------------------------------------------------------------------------------------ misc
-def tokens(dtype, B=3, T=4, hw=36, D=728):
+def tokens(dtype, B=3, T=4, hw=36, D=728, pad=False):
     feats = rnd((B, T, hw, D), dtype, 1)
     space, temporal = rnd((1, 1, D), torch.float32, 2), rnd((1, 1, D), torch.float32, 3)
     pos = rnd((1, T, hw + 3, D), torch.float32, 4)          # declared grid larger than the input's
-    x = ops.tokens_fwd(feats, space, temporal, pos)
+    x = ops.tokens_fwd(feats, space, temporal, pos, pad=pad)
     fd = feats.double().requires_grad_(True)
     sd, td, pd = (t.double().requires_grad_(True) for t in (space, temporal, pos))
     r = torch.cat((sd.view(1, 1, 1, D).expand(B, T, 1, D), fd), dim=2) + pd[:, :, :hw + 1]
@@ -189,6 +227,8 @@ def tokens(dtype, B=3, T=4, hw=36, D=728):
     dx = rnd(tuple(r.shape), dtype, 5)
     r.backward(dx.double())
     ds, dt, dp = torch.zeros_like(space), torch.zeros_like(temporal), torch.zeros_like(pos)
+    if pad:
+        dx = padded(dx.reshape(-1, D)).view(B, -1, D)
     dfe = ops.tokens_bwd(dx, B, T, hw, D, ds, dt, dp, True)
     e = max(relerr(x, r), relerr(dfe, fd.grad), relerr(ds, sd.grad), relerr(dt, td.grad), relerr(dp, pd.grad))
     return e, TOL[dtype]
@@ -211,6 +251,10 @@ def all_checks():
             out.append(('gemm_exact_big_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 515, 728, 1544)))
         for mode in ('fwd_bias_res', 'fwd_gelu', 'dgrad_gelu', 'wgrad', 'head'):
             out.append(('gemm_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_real(dt, mode)))
+        out.append(('gemm_padded_rows_%s' % tag, lambda dt=dt: gemm_padded(dt)))
+        out.append(('layernorm_padded_rows_%s' % tag, lambda dt=dt: layernorm(dt, pad=True)))
+        out.append(('layernorm_diff_padded_rows_%s' % tag, lambda dt=dt: layernorm_diff(dt, pad=True)))
+        out.append(('tokens_padded_rows_%s' % tag, lambda dt=dt: tokens(dt, pad=True)))
         out.append(('layernorm_%s' % tag, lambda dt=dt: layernorm(dt)))
         out.append(('layernorm_d64_%s' % tag, lambda dt=dt: layernorm(dt, 64, 77)))
         out.append(('layernorm_diff_%s' % tag, lambda dt=dt: layernorm_diff(dt)))
