@@ -15,7 +15,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     const long r1 = min(M, r0 + rows_per_block);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (col < N) {
-        for (long m = r0 + wid; m < r1; m += 4) {
+        // four rows in flight per wavefront: one dependent load per iteration left the kernel latency-bound
+        long m = r0 + wid;
+        for (; m + 12 < r1; m += 16) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8(x + m * ld + col, v0);
+            load8(x + (m + 4) * ld + col, v1);
+            load8(x + (m + 8) * ld + col, v2);
+            load8(x + (m + 12) * ld + col, v3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+        }
+        for (; m < r1; m += 4) {
             float v[8];
             load8(x + m * ld + col, v);
 #pragma unroll
@@ -33,8 +44,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 
 extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, hipStream_t stream) {
     if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0) return ISTVT_ERR_SHAPE;
-    int rpb = (int)((M + 255) / 256);
-    if (rpb < 64) rpb = 64;
+    int rpb = (int)((M + 1023) / 1024);      // ~1024 row blocks x column blocks: enough workgroups to fill 256 CUs
+    if (rpb < 32) rpb = 32;
     dim3 grid((N + 511) / 512, (unsigned)((M + rpb - 1) / rpb)), block(256);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)x, out, M, N, ld, rpb));
     return istvt_check_launch();

@@ -119,7 +119,7 @@ class LinearFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        w = ops.weight_as(weight, dy.dtype)
+        w = ops.weight_as(weight, dy.dtype, pad=True)       # the forward's operand copy: W^T is derived from it once
         dx = ops.linear_dgrad(dy, w, pad=True) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dy, x, weight) if ctx.needs_input_grad[1] else None
         db = _bgrad(dy, bias) if (bias is not None and ctx.needs_input_grad[2]) else None
@@ -142,10 +142,10 @@ class FeedForwardFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, u, g, w1, b1, w2, b2 = ctx.saved_tensors
-        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype), gelu_u=u, pad=True)       # (dy W2) * gelu'(u)
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True)       # (dy W2) * gelu'(u)
         dw2 = _wgrad(dy, g, w2)
         db2 = _bgrad(dy, b2)
-        dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype), pad=True) if ctx.needs_input_grad[0] else None
+        dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype, pad=True), pad=True) if ctx.needs_input_grad[0] else None
         dw1 = _wgrad(du, x, w1)
         db1 = _bgrad(du, b1)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)

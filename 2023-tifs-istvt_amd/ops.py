@@ -127,6 +127,29 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
 # bench.py sets this to a list to time every GEMM launch with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_flops, (a_kc, b_kc), (M, N, K)).
 gemm_profile = None
+# likewise for the memory-bound / attention kernels: entries are (name, start_event, end_event, algorithmic_bytes,
+# algorithmic_flops); bench.py turns them into achieved GB/s and TFLOP/s per kernel class.
+kernel_profile = None
+
+
+class prof:
+    """with prof('ln_fwd', nbytes): <launch>  -- records events on the launch stream when bench.py asks for it"""
+
+    def __init__(self, name, nbytes=0, flops=0):
+        self.rec = (name, nbytes, flops) if kernel_profile is not None else None
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None and kernel_profile is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            kernel_profile.append((self.rec[0], self.e0, e1, self.rec[1], self.rec[2]))
+        return False
 
 
 def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residual=None, bias=None, out_mode=0,
@@ -144,7 +167,11 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
             if q_ok and os.environ.get('ISTVT_GEMM_Q', '1') != '0':
                 return 'gemm256q_kernel<%d, %s, 0>' % (epi, side)
             return 'gemm256p_kernel<%d, %s>' % (epi, side)
-        return 'gemm256r_kernel<false, 0>' if a_kc else 'gemm256_kernel<true, 0>'
+        if a_kc:
+            return 'gemm256r_kernel<false, 0>'
+        t_ok = (out_mode == 3 and bias is None and residual is None and epi == 0 and K * lda * 2 < 0x7fffffff
+                and K * ldb * 2 < 0x7fffffff and os.environ.get('ISTVT_GEMM_T', '1') != '0')
+        return 'gemm256t_kernel' if t_ok else 'gemm256_kernel<true, 0>'
     t = '__bf16' if A.dtype == torch.bfloat16 else 'float'
     return 'gemm_kernel<%s, %s, %s>' % (t, str(bool(a_kc)).lower(), str(bool(b_kc)).lower())
 
@@ -292,7 +319,8 @@ def colsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     if out is None:
         out = torch.zeros((N,), dtype=torch.float32, device=x.device)
     if N % 8 == 0:
-        _lib.check(_lib.lib().istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, ld, dtype_code(x), _stream()), 'istvt_colsum')
+        with prof('colsum', M * N * x.element_size()):
+            _lib.check(_lib.lib().istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, ld, dtype_code(x), _stream()), 'istvt_colsum')
     else:
         x = _c(x)
         # narrow outputs (e.g. the 1-logit head): a [N][1] GEMM against ones keeps it on the HIP path
@@ -311,9 +339,10 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, pad: bool 
     y = empty_rows(M, D, x.dtype, x.device, pad)
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _lib.check(_lib.lib().istvt_layernorm_fwd(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                              y.stride(0) if M > 1 else D, mean.data_ptr(), rstd.data_ptr(), M, D, eps,
-                                              dtype_code(x), _stream()), 'istvt_layernorm_fwd')
+    with prof('ln_fwd', 2 * M * D * x.element_size()):
+        _lib.check(_lib.lib().istvt_layernorm_fwd(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                  y.stride(0) if M > 1 else D, mean.data_ptr(), rstd.data_ptr(), M, D, eps,
+                                                  dtype_code(x), _stream()), 'istvt_layernorm_fwd')
     return (y if x.dim() == 2 else y.view(*x.shape)), mean, rstd
 
 
@@ -326,10 +355,11 @@ def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: in
     diff = empty_rows(M, D, x.dtype, x.device, pad)
     mean = torch.empty((M,), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                                   y.stride(0), diff.data_ptr(), diff.stride(0), mean.data_ptr(),
-                                                   rstd.data_ptr(), B, F, P, D, eps, dtype_code(x), _stream()),
-               'istvt_layernorm_fwd_diff')
+    with prof('ln_fwd_diff', 3 * M * D * x.element_size()):
+        _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                       y.stride(0), diff.data_ptr(), diff.stride(0), mean.data_ptr(),
+                                                       rstd.data_ptr(), B, F, P, D, eps, dtype_code(x), _stream()),
+                   'istvt_layernorm_fwd_diff')
     return y, diff, mean, rstd
 
 
@@ -345,10 +375,12 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
     if dres is not None:
         dres, ld_res = rows(dres)
     dx = empty_rows(M, D, x.dtype, x.device, pad)
-    _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), ld_dy, _ptr(dy2), ld_dy2, x2.data_ptr(), ldx, mean.data_ptr(),
-                                              rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(),
-                                              dx.stride(0) if M > 1 else D, dgamma.data_ptr(), dbeta.data_ptr(), M, D, F,
-                                              P, dtype_code(x), _stream()), 'istvt_layernorm_bwd')
+    ntens = 3 + (dy2 is not None) + (dres is not None)          # dy, x, dx (+ dy2 once: its shifted re-read hits L2) (+ dres)
+    with prof('ln_bwd', ntens * M * D * x.element_size()):
+        _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), ld_dy, _ptr(dy2), ld_dy2, x2.data_ptr(), ldx, mean.data_ptr(),
+                                                  rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(),
+                                                  dx.stride(0) if M > 1 else D, dgamma.data_ptr(), dbeta.data_ptr(), M, D, F,
+                                                  P, dtype_code(x), _stream()), 'istvt_layernorm_bwd')
     return dx if x.dim() == 2 else dx.view(*x.shape)
 
 
@@ -360,8 +392,9 @@ def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int):
         raise RuntimeError('attn_spatial: qkv %s is not (%d*%d, 3*%d)' % (tuple(qkv.shape), BF, P, inner))
     out = torch.empty((BF * P, inner), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((BF * P, heads, 2), dtype=torch.float32, device=qkv.device)   # (row max [log2], 1/rowsum)
-    _lib.check(_lib.lib().istvt_attn_spatial_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh,
-                                                 dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_fwd')
+    with prof('attn_spatial_fwd', 4 * BF * P * inner * qkv.element_size(), 4.0 * BF * heads * P * P * dh):
+        _lib.check(_lib.lib().istvt_attn_spatial_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh,
+                                                     dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_fwd')
     return out, lse
 
 
@@ -369,9 +402,11 @@ def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: in
     dout = _c(_req(dout))
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().istvt_attn_spatial_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                                 delta.data_ptr(), dqkv.data_ptr(), BF, P, heads, dh, dh ** -0.5,
-                                                 dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
+    inner = heads * dh
+    with prof('attn_spatial_bwd', 8 * BF * P * inner * qkv.element_size(), 10.0 * BF * heads * P * P * dh):
+        _lib.check(_lib.lib().istvt_attn_spatial_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                                     delta.data_ptr(), dqkv.data_ptr(), BF, P, heads, dh, dh ** -0.5,
+                                                     dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
     return dqkv
 
 
@@ -383,9 +418,10 @@ def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int,
     if qk.numel() != B * F * P * 2 * inner or v.numel() != B * F * P * inner:
         raise RuntimeError('attn_temporal: shapes %s / %s do not match B=%d F=%d P=%d' % (tuple(qk.shape), tuple(v.shape), B, F, P))
     out = torch.empty((B * F * P, inner), dtype=qk.dtype, device=qk.device)
-    _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), v.data_ptr(), out.data_ptr(), B, F, P,
-                                                  heads, dh, dh ** -0.5, dtype_code(qk), _stream()),
-               'istvt_attn_temporal_fwd')
+    with prof('attn_temporal_fwd', 4 * B * F * P * inner * qk.element_size(), 4.0 * B * P * heads * F * F * dh):
+        _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), v.data_ptr(), out.data_ptr(), B, F, P,
+                                                      heads, dh, dh ** -0.5, dtype_code(qk), _stream()),
+                   'istvt_attn_temporal_fwd')
     return out
 
 
@@ -393,9 +429,10 @@ def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: in
     dout = _c(_req(dout))
     dqk = torch.empty_like(qk)
     dv = torch.empty_like(v)
-    _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), v.data_ptr(), dout.data_ptr(),
-                                                  dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
-                                                  dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
+    with prof('attn_temporal_bwd', 7 * B * F * P * heads * dh * qk.element_size(), 10.0 * B * P * heads * F * F * dh):
+        _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), v.data_ptr(), dout.data_ptr(),
+                                                      dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
+                                                      dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
     return dqk, dv
 
 

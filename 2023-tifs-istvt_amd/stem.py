@@ -117,13 +117,16 @@ def dwconv(x: Tensor, w9: Tensor, Fr: int, H: int, W: int, C: int, *, in_bn: Opt
     """stats ([2][C] fp64, accumulated): fused BatchNorm-backward sums of the OUTPUT w.r.t. `m_bn`."""
     out = torch.empty((Fr * H * W, C), dtype=x.dtype, device=x.device)
     Ha, Wa = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    _lib.check(_lib.lib().istvt_dwconv3x3(
-        x.data_ptr(), w9.data_ptr(), out.data_ptr(), Fr, H, W, C,
-        in_bn.ptr() if in_bn else None, int(in_relu), int(flip),
-        _ptr(msrc), m_bn.ptr() if m_bn else None, int(mask_pre), int(mask_post),
-        _ptr(addsrc), Ha, Wa,
-        stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None,
-        dtype_code(x), _stream()), 'istvt_dwconv3x3')
+    nel = Fr * H * W * C
+    nbytes = (2 * nel + (nel if msrc is not None else 0) + (nel // 4 if addsrc is not None else 0)) * x.element_size()
+    with ops.prof('dwconv3x3', nbytes, 18.0 * nel):
+        _lib.check(_lib.lib().istvt_dwconv3x3(
+            x.data_ptr(), w9.data_ptr(), out.data_ptr(), Fr, H, W, C,
+            in_bn.ptr() if in_bn else None, int(in_relu), int(flip),
+            _ptr(msrc), m_bn.ptr() if m_bn else None, int(mask_pre), int(mask_post),
+            _ptr(addsrc), Ha, Wa,
+            stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None,
+            dtype_code(x), _stream()), 'istvt_dwconv3x3')
     return out
 
 

@@ -31,6 +31,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s is the measured copy rate)
 GF_PER_CLIP_FWD_BWD = {8: 1021.1, 16: 1938.7}     # SURVEY.md 8(a), T=8 / T=16 at 224^2, depth 12
 
 
@@ -138,11 +139,26 @@ def main():
 
     # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
     roof = None
+    kern = None
     if rank == 0 and not a.no_kernel_profile:
         ops.gemm_profile = []
+        ops.kernel_profile = []
         step()
         torch.cuda.synchronize(dev)
         recs, ops.gemm_profile = ops.gemm_profile, None
+        krecs, ops.kernel_profile = ops.kernel_profile, None
+        # memory-bound and attention kernel classes: achieved GB/s (algorithmic bytes) and TFLOP/s per class
+        agg = {}
+        for name, e0, e1, nbytes, flops in krecs:
+            d = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += nbytes
+            d[2] += flops
+            d[3] += 1
+        kern = {k: {'ms_per_step': round(v[0] * 1e3, 3), 'launches': v[3], 'GBps': round(v[1] / v[0] / 1e9, 1),
+                    'frac_hbm_peak': round(v[1] / v[0] / 1e9 / PEAK_HBM_GBPS, 3),
+                    **({'TFLOPs': round(v[2] / v[0] / 1e12, 2)} if k.startswith('attn_spatial') else {})}
+                for k, v in agg.items() if v[0] > 0}
         by = {}                                   # rocprof kernel name -> [flops, seconds, launches]
         for ev0, ev1, flops, variant, shape, kname in recs:
             d = by.setdefault(kname, [0.0, 0.0, 0])
@@ -167,7 +183,8 @@ def main():
         pmc = os.path.join(ROOT, 'profiles', 'pmc', 'r01_pmc_whole_step_summary.json')
         is_c2 = (a.batch, a.frames, a.size, a.depth, a.dtype) == (32, 8, 224, 12, 'bf16')
         if is_c2 and os.path.exists(pmc):
-            rec = json.load(open(pmc)).get('void ' + dom)
+            table = json.load(open(pmc))
+            rec = table.get('void ' + dom + '(GemmArgs)') or table.get(dom + '(GemmArgs)') or table.get('void ' + dom)
             if rec and 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
                 roof['traffic'] = round((2.0 * rec['FETCH_SIZE']['avg_KB'] + rec['WRITE_SIZE']['avg_KB']) * 1024)
                 roof['traffic_unit'] = 'bytes/launch (rocprofv3 --pmc, profiles/pmc/)'
@@ -191,6 +208,8 @@ def main():
             out['model_mfma_frac'] = round(value / world * gf / 1e3 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS), 4)
         if roof:
             out['roofline'] = roof
+        if kern:
+            out['kernels'] = kern
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
         print(json.dumps(out), flush=True)
