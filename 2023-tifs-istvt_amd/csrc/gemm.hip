@@ -317,6 +317,10 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                     case 5: hipLaunchKernelGGL((gemm256q_kernel<0, false, 5>), dim3(G), block, 0, stream, a); break;
                     case 6: hipLaunchKernelGGL((gemm256q_kernel<0, false, 6>), dim3(G), block, 0, stream, a); break;
                     case 7: hipLaunchKernelGGL((gemm256q_kernel<0, false, 7>), dim3(G), block, 0, stream, a); break;
+                    case 16: hipLaunchKernelGGL((gemm256q_kernel<0, false, 16>), dim3(G), block, 0, stream, a); break;
+                    case 32: hipLaunchKernelGGL((gemm256q_kernel<0, false, 32>), dim3(G), block, 0, stream, a); break;
+                    case 48: hipLaunchKernelGGL((gemm256q_kernel<0, false, 48>), dim3(G), block, 0, stream, a); break;
+                    case 80: hipLaunchKernelGGL((gemm256q_kernel<0, false, 80>), dim3(G), block, 0, stream, a); break;
                     default: hipLaunchKernelGGL((gemm256q_kernel<0, false, 8>), dim3(G), block, 0, stream, a); break;
                 }
                 return istvt_check_launch();

@@ -220,6 +220,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             const char* ua_hi = ubase + 3 * QU_BYTES;
             const char* ub = ubase + b_unit * QU_BYTES;
             bf16x8 af[4][2], bq[4][2];
+            // (no s_setprio around the MFMAs: raising the computing wave's priority starved its SIMD partner's load slot,
+            //  measured -4..6 % on the model's shapes; raising the loader's instead -4 %)
             auto mma = [&](const int mt0) {
                 if (DBG & 2) {
 #pragma unroll
@@ -228,7 +230,6 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                         for (int t = 0; t < 4; ++t) { asm volatile("" ::"v"(af[t][kh])); asm volatile("" ::"v"(bq[t][kh])); }
                     return;
                 }
-                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -236,7 +237,6 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
                             acc[mt0 + t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt0 + t][nt], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
             };
             auto load_a = [&](const char* base) {
 #pragma unroll
@@ -251,6 +251,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 }
             };
             // ---- phase A: AL x B
+            if (DBG & 64) __builtin_amdgcn_s_setprio(1);
+            if (DBG & 32) { issue_pair(2); __builtin_amdgcn_sched_barrier(0); }
             load_a(ua_lo);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -268,16 +270,19 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 const int col = min(bn0 + wn * 64 + lane, p.N - 1);
                 __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)slab, 4, 0, 0);
             }
-            issue_pair(2);                                                   // units U0+6, U0+7
+            if (!(DBG & 32)) issue_pair(2);                                  // units U0+6, U0+7
             // unit U0+3 (AH) landed: all but the 4 younger units (8 pieces); fewer exist only when the stream ends
             if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
+            if (DBG & 64) __builtin_amdgcn_s_setprio(0);
             slot_barrier();
             mma(0);
             slot_barrier();
             // ---- phase B: AH x B
+            if (DBG & 64) __builtin_amdgcn_s_setprio(1);
+            if (DBG & 32) { issue_pair(0); __builtin_amdgcn_sched_barrier(0); }
             load_a(ua_hi);
-            issue_pair(0);                                                   // units U0+8, U0+9
+            if (!(DBG & 32)) issue_pair(0);                                  // units U0+8, U0+9
             if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
             // units <= U0+6 (the next K tile's AL, BL, BH) landed; the side loads just issued are younger still
             if (total_u - 1 - (U0 + 6) >= 3) {
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             } else {
                 wait_vm_n(2 * max(0, total_u - 1 - (U0 + 6)) + ((last && HAS_SIDE) ? 4 : 0));
             }
+            if (DBG & 64) __builtin_amdgcn_s_setprio(0);
             slot_barrier();
             mma(4);
             slot_barrier();

@@ -121,7 +121,6 @@ __global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
         const char* ub = ubase + b_unit * QU_BYTES;
         bf16x8 af[4][2], bq[4][2];
         auto mma = [&](const int mt0) {
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -129,7 +128,6 @@ __global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt0 + t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt0 + t][nt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
         };
         auto load_a = [&](const char* base) {
 #pragma unroll
