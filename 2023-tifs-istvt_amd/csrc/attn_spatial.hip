@@ -20,6 +20,7 @@
 //   sattn_bwd_dkv: one wavefront owns 32 keys; queries stream through LDS;
 //                  dV^T += dO^T P ; dK^T += Q^T dS
 #include "common.h"
+#include <cstdlib>
 
 constexpr int CHUNK = 128;          // rows of an LDS image
 constexpr int NT = CHUNK / 16;      // 16-row tiles per chunk
@@ -29,14 +30,14 @@ constexpr int IPAD = 8;             // row padding (elements)
 
 // copy rows [row0, row0+CHUNK) x DH columns of a [rows][ld] matrix into an LDS image, zero-filling
 // rows >= nrows
-template <typename T, int DH>
+template <typename T, int DH, int NTHR = 256>
 __device__ __forceinline__ void stage_img(T* img, const T* __restrict__ src, long ld, int row0, int nrows, int tid) {
     constexpr int LDI = DH + IPAD;
     constexpr int VPR = DH / 8;
-    constexpr int NV = CHUNK * VPR / 256;
+    constexpr int NV = CHUNK * VPR / NTHR;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = tid + 256 * i;
+        const int v = tid + NTHR * i;
         const int row = v / VPR, col = (v % VPR) * 8;
         typename Mma<T>::frag f;
         if (row0 + row < nrows) f = frag_load(src + (long)(row0 + row) * ld + col);
@@ -77,8 +78,11 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+// U = query tiles (of 16) per wavefront, 128 / (16 U) wavefronts per workgroup.  U = 1 (8 wavefronts) halves the
+// registers of a wavefront: 4 instead of 2 wavefronts per SIMD, whose softmax (VALU) and MFMA phases then overlap and
+// whose staging latencies hide each other (the kernel is bound by neither pipe: it waits).
+template <typename T, int DH, int U>
+__global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         float* __restrict__ lse, int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
@@ -92,43 +96,48 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const T* __restrict__ qk
     const T* qp = base + h * DH;
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * 128 + wave * 16 * U;
     const bool active = q0 < P;
     const float c = scale * LOG2E;
 
-    typename Mma<T>::frag qf[2][KS];
+    typename Mma<T>::frag qf[U][KS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[u][ks] = row_frag<T>(qp, ld, q0 + 16 * u + r, P, 32 * ks + 8 * g);
 
-    f32x4 o[DT][2];
+    f32x4 o[DT][U];
+    float m_run[U], l_run[U];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4{0, 0, 0, 0}; o[dt][1] = f32x4{0, 0, 0, 0}; }
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int u = 0; u < U; ++u) {
+        m_run[u] = -INFINITY; l_run[u] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt][u] = f32x4{0, 0, 0, 0};
+    }
 
     for (int c0 = 0; c0 < P; c0 += CHUNK) {
         if (c0) __syncthreads();
-        stage_img<T, DH>(Kimg, kp, ld, c0, P, tid);
-        stage_img<T, DH>(Vimg, vp, ld, c0, P, tid);
+        stage_img<T, DH, 512 / U>(Kimg, kp, ld, c0, P, tid);
+        stage_img<T, DH, 512 / U>(Vimg, vp, ld, c0, P, tid);
         __syncthreads();
         if (!active) continue;
-        f32x4 s[NT][2];
+        f32x4 s[NT][U];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            s[t][0] = f32x4{0, 0, 0, 0}; s[t][1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[t][u] = f32x4{0, 0, 0, 0};
             if (c0 + 16 * t < P) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     typename Mma<T>::frag kf = frag_load(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
-                    Mma<T>::mma(s[t][0], kf, qf[0][ks]);
-                    Mma<T>::mma(s[t][1], kf, qf[1][ks]);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) Mma<T>::mma(s[t][u], kf, qf[u][ks]);
                 }
             }
         }
         // online softmax in the log2 domain; lane owns query r of sub-tile u, keys 4g+j of each tile
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -161,21 +170,22 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const T* __restrict__ qk
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss < P) {
-                typename Mma<T>::frag p0 = acc_frag<T>(s[2 * ss][0], s[2 * ss + 1][0]);
-                typename Mma<T>::frag p1 = acc_frag<T>(s[2 * ss][1], s[2 * ss + 1][1]);
+                typename Mma<T>::frag pf[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) pf[u] = acc_frag<T>(s[2 * ss][u], s[2 * ss + 1][u]);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     typename Mma<T>::frag vf =
                         frag_load_tr(Vimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
-                    Mma<T>::mma(o[dt][0], vf, p0);
-                    Mma<T>::mma(o[dt][1], vf, p1);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) Mma<T>::mma(o[dt][u], vf, pf[u]);
                 }
             }
         }
     }
     if (!active) return;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int q = q0 + 16 * u + r;
         if (q >= P) continue;
         const float inv = 1.0f / l_run[u];
@@ -197,8 +207,8 @@ __global__ __launch_bounds__(256) void sattn_fwd_kernel(const T* __restrict__ qk
 
 // ------------------------------------------------------------------------------------------
 // backward part 1: delta = rowsum(dO o O), dQ
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+template <typename T, int DH, int U>
+__global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv, int P,
                                                            int heads, float scale) {
@@ -216,14 +226,14 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
     const T* vp = base + 2 * inner + h * DH;
     const T* op = out + (long)bf * P * inner + h * DH;
     const T* dop = dout + (long)bf * P * inner + h * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * 128 + wave * 16 * U;
     const bool active = q0 < P;
     const float c = scale * LOG2E;
 
-    typename Mma<T>::frag qf[2][KS], dof[2][KS];
-    float lq[2], li[2], dl[2];
+    typename Mma<T>::frag qf[U][KS], dof[U][KS];
+    float lq[U], li[U], dl[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int q = q0 + 16 * u + r;
         float part = 0.f;
 #pragma unroll
@@ -244,36 +254,39 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
         if (q < P && g == 0) delta[((long)bf * P + q) * heads + h] = dl[u];
     }
 
-    f32x4 dq[DT][2];
+    f32x4 dq[DT][U];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0, 0, 0, 0}; dq[dt][1] = f32x4{0, 0, 0, 0}; }
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int u = 0; u < U; ++u) dq[dt][u] = f32x4{0, 0, 0, 0};
 
     for (int c0 = 0; c0 < P; c0 += CHUNK) {
         if (c0) __syncthreads();
-        stage_img<T, DH>(Kimg, kp, ld, c0, P, tid);
-        stage_img<T, DH>(Vimg, vp, ld, c0, P, tid);
+        stage_img<T, DH, 512 / U>(Kimg, kp, ld, c0, P, tid);
+        stage_img<T, DH, 512 / U>(Vimg, vp, ld, c0, P, tid);
         __syncthreads();
         if (!active) continue;
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss >= P) continue;
-            f32x4 s[2][2], dp[2][2];
+            f32x4 s[2][U], dp[2][U];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                s[tt][0] = f32x4{0, 0, 0, 0}; s[tt][1] = f32x4{0, 0, 0, 0};
-                dp[tt][0] = f32x4{0, 0, 0, 0}; dp[tt][1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < U; ++u) { s[tt][u] = f32x4{0, 0, 0, 0}; dp[tt][u] = f32x4{0, 0, 0, 0}; }
                 const int krow = 32 * ss + 16 * tt + r;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     typename Mma<T>::frag kf = frag_load(Kimg + krow * LDI + 32 * ks + 8 * g);
                     typename Mma<T>::frag vf = frag_load(Vimg + krow * LDI + 32 * ks + 8 * g);
-                    Mma<T>::mma(s[tt][0], kf, qf[0][ks]);
-                    Mma<T>::mma(s[tt][1], kf, qf[1][ks]);
-                    Mma<T>::mma(dp[tt][0], vf, dof[0][ks]);
-                    Mma<T>::mma(dp[tt][1], vf, dof[1][ks]);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        Mma<T>::mma(s[tt][u], kf, qf[u][ks]);
+                        Mma<T>::mma(dp[tt][u], vf, dof[u][ks]);
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int key = c0 + 32 * ss + 16 * tt + 4 * g + j;
@@ -281,19 +294,20 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
                         s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]) * scale;       // dS^T
                     }
             }
-            typename Mma<T>::frag ds0 = acc_frag<T>(s[0][0], s[1][0]);
-            typename Mma<T>::frag ds1 = acc_frag<T>(s[0][1], s[1][1]);
+            typename Mma<T>::frag dsf[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dsf[u] = acc_frag<T>(s[0][u], s[1][u]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 typename Mma<T>::frag kt = frag_load_tr(Kimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
-                Mma<T>::mma(dq[dt][0], kt, ds0);
-                Mma<T>::mma(dq[dt][1], kt, ds1);
+#pragma unroll
+                for (int u = 0; u < U; ++u) Mma<T>::mma(dq[dt][u], kt, dsf[u]);
             }
         }
     }
     if (!active) return;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int q = q0 + 16 * u + r;
         if (q >= P) continue;
         T* dqp = dqkv + ((long)bf * P + q) * ld + h * DH;
@@ -307,8 +321,8 @@ __global__ __launch_bounds__(256) void sattn_bwd_dq_kernel(const T* __restrict__
 
 // ------------------------------------------------------------------------------------------
 // backward part 2: dK, dV.  Wave owns 32 keys; queries stream through LDS.
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+template <typename T, int DH, int U>
+__global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
                                                             int P, int heads, float scale) {
@@ -326,29 +340,28 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
     const T* dop = dout + (long)bf * P * inner + h * DH;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = blockIdx.x * 128 + wave * 16 * U;
     const bool active = k0 < P;
     const float c = scale * LOG2E;
 
-    typename Mma<T>::frag kf[2][KS], vf[2][KS];
+    typename Mma<T>::frag kf[U][KS], vf[U][KS];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < U; ++kt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kf[kt][ks] = row_frag<T>(kp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
             vf[kt][ks] = row_frag<T>(vp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
         }
-    f32x4 dk[DT][2], dv[DT][2];
+    f32x4 dk[DT][U], dv[DT][U];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        dk[dt][0] = f32x4{0, 0, 0, 0}; dk[dt][1] = f32x4{0, 0, 0, 0};
-        dv[dt][0] = f32x4{0, 0, 0, 0}; dv[dt][1] = f32x4{0, 0, 0, 0};
-    }
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < U; ++kt) { dk[dt][kt] = f32x4{0, 0, 0, 0}; dv[dt][kt] = f32x4{0, 0, 0, 0}; }
 
     for (int c0 = 0; c0 < P; c0 += CHUNK) {
         if (c0) __syncthreads();
-        stage_img<T, DH>(Qimg, qp, ld, c0, P, tid);
-        stage_img<T, DH>(Dimg, dop, inner, c0, P, tid);
+        stage_img<T, DH, 512 / U>(Qimg, qp, ld, c0, P, tid);
+        stage_img<T, DH, 512 / U>(Dimg, dop, inner, c0, P, tid);
         if (tid < CHUNK) {
             const int q = c0 + tid;
             const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h]
@@ -362,20 +375,21 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss >= P) continue;
-            f32x4 s[2][2], dp[2][2];      // [query tile tt][key tile kt]; rows = queries 4g+j, cols = keys r
+            f32x4 s[2][U], dp[2][U];      // [query tile tt][key tile kt]; rows = queries 4g+j, cols = keys r
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                s[tt][0] = f32x4{0, 0, 0, 0}; s[tt][1] = f32x4{0, 0, 0, 0};
-                dp[tt][0] = f32x4{0, 0, 0, 0}; dp[tt][1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < U; ++kt) { s[tt][kt] = f32x4{0, 0, 0, 0}; dp[tt][kt] = f32x4{0, 0, 0, 0}; }
                 const int qrow = 32 * ss + 16 * tt + r;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     typename Mma<T>::frag qa = frag_load(Qimg + qrow * LDI + 32 * ks + 8 * g);
                     typename Mma<T>::frag da = frag_load(Dimg + qrow * LDI + 32 * ks + 8 * g);
-                    Mma<T>::mma(s[tt][0], qa, kf[0][ks]);
-                    Mma<T>::mma(s[tt][1], qa, kf[1][ks]);
-                    Mma<T>::mma(dp[tt][0], da, vf[0][ks]);
-                    Mma<T>::mma(dp[tt][1], da, vf[1][ks]);
+#pragma unroll
+                    for (int kt = 0; kt < U; ++kt) {
+                        Mma<T>::mma(s[tt][kt], qa, kf[kt][ks]);
+                        Mma<T>::mma(dp[tt][kt], da, vf[kt][ks]);
+                    }
                 }
                 const int qb = 32 * ss + 16 * tt + 4 * g;
                 const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][qb]);
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
                 const float iv[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < U; ++kt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float pv = fast_exp2(s[tt][kt][j] * c - lv[j]) * iv[j];
@@ -392,24 +406,24 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
                         dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]) * scale;     // dS
                     }
             }
-            typename Mma<T>::frag p0 = acc_frag<T>(s[0][0], s[1][0]);
-            typename Mma<T>::frag p1 = acc_frag<T>(s[0][1], s[1][1]);
-            typename Mma<T>::frag ds0 = acc_frag<T>(dp[0][0], dp[1][0]);
-            typename Mma<T>::frag ds1 = acc_frag<T>(dp[0][1], dp[1][1]);
+            typename Mma<T>::frag pf[U], dsf[U];
+#pragma unroll
+            for (int kt = 0; kt < U; ++kt) { pf[kt] = acc_frag<T>(s[0][kt], s[1][kt]); dsf[kt] = acc_frag<T>(dp[0][kt], dp[1][kt]); }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 typename Mma<T>::frag dot_ = frag_load_tr(Dimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
                 typename Mma<T>::frag qt_ = frag_load_tr(Qimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
-                Mma<T>::mma(dv[dt][0], dot_, p0);
-                Mma<T>::mma(dv[dt][1], dot_, p1);
-                Mma<T>::mma(dk[dt][0], qt_, ds0);
-                Mma<T>::mma(dk[dt][1], qt_, ds1);
+#pragma unroll
+                for (int kt = 0; kt < U; ++kt) {
+                    Mma<T>::mma(dv[dt][kt], dot_, pf[kt]);
+                    Mma<T>::mma(dk[dt][kt], qt_, dsf[kt]);
+                }
             }
         }
     }
     if (!active) return;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < U; ++kt) {
         const int key = k0 + 16 * kt + r;
         if (key >= P) continue;
         T* dkp = dqkv + ((long)bf * P + key) * ld + inner + h * DH;
@@ -436,8 +450,16 @@ __global__ __launch_bounds__(256) void sattn_bwd_dkv_kernel(const T* __restrict_
 extern "C" int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh,
                                       float scale, int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    dim3 grid((P + 127) / 128, BF * heads), block(256);
-    DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<T, DH>), grid, block, 0, stream,
+    dim3 grid((P + 127) / 128, BF * heads);
+    static const int u1 = getenv("ISTVT_SATTN_U") ? atoi(getenv("ISTVT_SATTN_U")) : 1;
+    // bf16: 8 wavefronts x 16 queries (more wavefronts per SIMD); fp32 keeps 4 x 32 (its LDS image fills the CU)
+    if (dtype == DT_BF16 && u1 == 1) {
+        DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream,
+                                           (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+        return istvt_check_launch();
+    }
+    dim3 block(256);
+    DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<T, DH, 2>), grid, block, 0, stream,
                                                              (const T*)qkv, (T*)out, lse, P, heads, scale)));
     return istvt_check_launch();
 }
@@ -447,11 +469,22 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, const void* out, const vo
                                       float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale,
                                       int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    dim3 grid((P + 127) / 128, BF * heads), block(256);
+    dim3 grid((P + 127) / 128, BF * heads);
+    static const int u1 = getenv("ISTVT_SATTN_U") ? atoi(getenv("ISTVT_SATTN_U")) : 1;
+    if (dtype == DT_BF16 && u1 == 1) {          // 8 wavefronts x 16 rows, see sattn_fwd_kernel
+        DISPATCH_DH(dh, {
+            hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
+                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+            hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
+                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+        });
+        return istvt_check_launch();
+    }
+    dim3 block(256);
     DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, {
-        hipLaunchKernelGGL((sattn_bwd_dq_kernel<T, DH>), grid, block, 0, stream, (const T*)qkv, (const T*)out,
+        hipLaunchKernelGGL((sattn_bwd_dq_kernel<T, DH, 2>), grid, block, 0, stream, (const T*)qkv, (const T*)out,
                            (const T*)dout, lse, delta, (T*)dqkv, P, heads, scale);
-        hipLaunchKernelGGL((sattn_bwd_dkv_kernel<T, DH>), grid, block, 0, stream, (const T*)qkv, (const T*)dout, lse,
+        hipLaunchKernelGGL((sattn_bwd_dkv_kernel<T, DH, 2>), grid, block, 0, stream, (const T*)qkv, (const T*)dout, lse,
                            (const float*)delta, (T*)dqkv, P, heads, scale);
     }));
     return istvt_check_launch();
