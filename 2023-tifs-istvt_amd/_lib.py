@@ -45,6 +45,7 @@ SIGNATURES = {
     'istvt_colsum': [P, P, L, I, L, I, P],
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
+    'istvt_cast_transpose': [P, L, P, L, P, L, I, I, P],
 }
 
 _lib = None

@@ -246,3 +246,44 @@ extern "C" int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, i
     else return ISTVT_ERR_DTYPE;
     return istvt_check_launch();
 }
+
+// fp32 master weight [R][C] -> bf16 copy [R][C] AND its transpose [C][R], both with caller-given (line-aligned) row
+// strides, in one pass over the fp32 data: the forward GEMM reads W as its B operand, the input-gradient GEMM reads
+// W^T the same way.  (Separately: a cast kernel plus a strided torch copy per weight, 0.8 ms per step for the copies.)
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ in, long ldi,
+                                                             bf16_t* __restrict__ out, long ldo,
+                                                             bf16_t* __restrict__ outT, long ldt, int R, int C) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int row = threadIdx.x >> 2, cc = (threadIdx.x & 3) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = c0 + cc + 8 * h;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool ok = r0 + row < R && col < C;
+        if (ok) load8(in + (long)(r0 + row) * ldi + col, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[row][cc + 8 * h + j] = v[j];
+        if (ok) store8(out + (long)(r0 + row) * ldo + col, v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int tr = c0 + row;                 // row of the transpose = column of the input
+        const int tc = r0 + cc + 8 * h;
+        if (tr < C && tc < R) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[cc + 8 * h + j][row];
+            store8(outT + (long)tr * ldt + tc, v);
+        }
+    }
+}
+
+extern "C" int istvt_cast_transpose(const float* in, long ldi, void* out, long ldo, void* outT, long ldt, int R, int C,
+                                    hipStream_t stream) {
+    if (R <= 0 || C <= 0 || R % 8 || C % 8 || ldi < C || ldo < C || ldt < R || ldi % 4 || ldo % 8 || ldt % 8) return ISTVT_ERR_SHAPE;
+    dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
+    hipLaunchKernelGGL(cast_transpose_kernel, grid, block, 0, stream, in, ldi, (bf16_t*)out, ldo, (bf16_t*)outT, ldt, R, C);
+    return istvt_check_launch();
+}

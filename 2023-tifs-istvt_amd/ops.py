@@ -114,9 +114,18 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
         return hit[2]
     if pad:
         w2 = _c(w2)
-        out = empty_rows(w2.shape[0], w2.shape[1], dtype, w2.device)
-        _lib.check(_lib.lib().istvt_cast2d(w2.data_ptr(), dtype_code(w2), w2.shape[1], out.data_ptr(), _DT[dtype],
-                                           out.stride(0), w2.shape[0], w2.shape[1], _stream()), 'istvt_cast2d')
+        R, C = w2.shape
+        out = empty_rows(R, C, dtype, w2.device)
+        if w2.dtype == torch.float32 and dtype == torch.bfloat16 and R % 8 == 0 and R >= G256_MIN and C >= G256_MIN:
+            # the operand of the input-gradient GEMM (W^T, k-contiguous) comes out of the same pass over the fp32 weight
+            wt = empty_rows(C, R, dtype, w2.device)
+            _lib.check(_lib.lib().istvt_cast_transpose(w2.data_ptr(), C, out.data_ptr(), out.stride(0), wt.data_ptr(),
+                                                       wt.stride(0), R, C, _stream()), 'istvt_cast_transpose')
+            tkey = (id(out), 'T')
+            _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey: _wcache.pop(k, None)), 0, wt)
+        else:
+            _lib.check(_lib.lib().istvt_cast2d(w2.data_ptr(), dtype_code(w2), C, out.data_ptr(), _DT[dtype],
+                                               out.stride(0), R, C, _stream()), 'istvt_cast2d')
     else:
         out = cast(w2, dtype)
     _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)

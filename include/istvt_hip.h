@@ -160,6 +160,10 @@ int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, i
 /* rows x cols cast between row-strided buffers (bf16 operand copies of fp32 weights with line-aligned rows) */
 int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtype, long ldo, long rows, int cols,
                  istvt_stream_t stream);
+/* fp32 [R][C] -> bf16 [R][C] (row stride ldo) and its transpose bf16 [C][R] (row stride ldt) in one pass: the
+ * operand copies of a Linear weight for the forward and the input-gradient GEMMs (R, C multiples of 8) */
+int istvt_cast_transpose(const float* in, long ldi, void* out, long ldo, void* outT, long ldt, int R, int C,
+                         istvt_stream_t stream);
 
 #ifdef __cplusplus
 }

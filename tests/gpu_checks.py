@@ -242,9 +242,20 @@ def colsum_cast(dtype):
     return e, TOL[dtype]
 
 
+def cast_transpose(R=1000, C=728):
+    """fp32 weight -> bf16 operand copy + its transpose (both with padded rows) in one pass; exact vs torch's cast"""
+    w = torch.nn.Parameter(rnd((R, C), torch.float32, 7))
+    wp = ops.weight_as(w, torch.bfloat16, pad=True)
+    wt = ops._transposed_operand(wp)
+    ref = w.detach().to(torch.bfloat16)
+    assert wp.stride(0) == ops.pad_ld(C) and wt.stride(0) == ops.pad_ld(R)
+    e = max(float((wp.float() - ref.float()).abs().max()), float((wt.float() - ref.float().t()).abs().max()))
+    return e, 0.0
+
+
 def all_checks():
     """-> list of (name, callable)"""
-    out = []
+    out = [('cast_transpose', cast_transpose), ('cast_transpose_tail', lambda: cast_transpose(520, 1544))]
     for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
         for mode in ('fwd', 'dgrad', 'wgrad'):
             out.append(('gemm_exact_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode)))
