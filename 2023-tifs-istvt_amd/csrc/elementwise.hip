@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 
 extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, hipStream_t stream) {
     if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0) return ISTVT_ERR_SHAPE;
-    int rpb = (int)((M + 1023) / 1024);      // ~1024 row blocks x column blocks: enough workgroups to fill 256 CUs
-    if (rpb < 32) rpb = 32;
+    // 256 row blocks: every block ends with one float atomic per column into the SAME N addresses, and same-address
+    // atomics serialise at the memory side (1024 row blocks were slower than 256 although the loads ran faster)
+    int rpb = (int)((M + 255) / 256);
+    if (rpb < 64) rpb = 64;
     dim3 grid((N + 511) / 512, (unsigned)((M + rpb - 1) / rpb)), block(256);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)x, out, M, N, ld, rpb));
     return istvt_check_launch();
