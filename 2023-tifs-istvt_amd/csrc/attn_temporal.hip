@@ -5,10 +5,15 @@
 // projected from the differenced LayerNorm output (see layernorm.hip).
 //
 // 0.1 % of the model's FLOPs and F x F tiles far below an MFMA tile: this is a data-movement
-// kernel, bound by HBM.  A cluster of CL = DH/4 lanes owns one (b,p,h); each lane keeps 4
-// consecutive head-dim elements of every frame's q/k/v row in registers, so a row segment
-// (DH elements) is one fully-coalesced cluster access, a wavefront touches 64/CL whole
-// DH-segments per instruction, dot products finish with log2(CL) DPP adds, no LDS.
+// kernel, bound by HBM.  A cluster of CL lanes owns one (b,p,h); each lane keeps EPL = DH/CL
+// consecutive head-dim elements of every frame's k/v row in registers, so a row segment
+// (DH elements) is one fully-coalesced cluster access, dot products finish with log2(CL) DPP /
+// swizzle adds, no LDS.
+//   F <= 9  : CL = DH/4 (4 elements per lane), every row of q,k,v(,dO) in registers (tattn_*_kernel)
+//   F <= 17 : CL = DH/2 (2 elements per lane) and the q / dO rows are fetched one frame ahead (tattn_*2_kernel)
+//             instead of held: with 4 elements per lane the F = 17 kernels needed 356 registers
+//             (560 bytes of scratch per lane, one wavefront per SIMD) and ran 13x slower for 2x
+//             the data (T = 16, BASELINE config 4).
 //
 // qk : [B*F*P][2*inner]  (q | k), v : [B*F*P][inner], out : [B*F*P][inner], rows ordered (b,f,p).
 // Nothing is saved for backward: the F x F probabilities are recomputed from q,k.
@@ -18,8 +23,10 @@ template <int CL> __device__ __forceinline__ float cluster_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
-    if (CL == 16)
+    if (CL >= 16)
         v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+    if (CL == 32)   // lanes i <-> i ^ 16 (ds_swizzle bit mode: and 0x1f, or 0, xor 0x10)
+        v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
     return v;
 }
 
@@ -179,30 +186,260 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
     }
 }
 
-#define DISPATCH_TATTN(KERNEL, ...)                                                                      \
+// ---- F <= 17: two elements per lane, q / dO rows fetched one frame ahead ---------------------------------
+// EPL (2 or 4) consecutive elements
+template <int EPL> __device__ __forceinline__ void loadE(const float* p, float (&v)[EPL]) {
+    if constexpr (EPL == 4) { const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+    else { const float2 a = *reinterpret_cast<const float2*>(p); v[0] = a.x; v[1] = a.y; }
+}
+template <int EPL> __device__ __forceinline__ void loadE(const bf16_t* p, float (&v)[EPL]) {
+    if constexpr (EPL == 4) {
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+    } else {
+        const unsigned u = *reinterpret_cast<const unsigned*>(p);
+        v[0] = __uint_as_float(u << 16);
+        v[1] = __uint_as_float(u & 0xffff0000u);
+    }
+}
+template <int EPL> __device__ __forceinline__ void storeE(float* p, const float (&v)[EPL]) {
+    if constexpr (EPL == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+}
+template <int EPL> __device__ __forceinline__ void storeE(bf16_t* p, const float (&v)[EPL]) {
+    if constexpr (EPL == 4) {
+        bf16x4 a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+        *reinterpret_cast<bf16x4*>(p) = a;
+    } else {
+        typedef bf16_t bf16x2v __attribute__((ext_vector_type(2)));
+        bf16x2v a;
+        a[0] = (bf16_t)v[0]; a[1] = (bf16_t)v[1];
+        *reinterpret_cast<bf16x2v*>(p) = a;
+    }
+}
+template <int EPL> __device__ __forceinline__ float dotE(const float (&a)[EPL], const float (&b)[EPL]) {
+    float s = a[0] * b[0];
+#pragma unroll
+    for (int e = 1; e < EPL; ++e) s += a[e] * b[e];
+    return s;
+}
+
+template <typename T, int DH, int FMAX, int EPL>
+__global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ qk, const T* __restrict__ v,
+                                                        T* __restrict__ out, int B, int F, int P, int heads,
+                                                        float scale) {
+    constexpr int CL = DH / EPL, GW = 64 / CL;
+    const int lane = threadIdx.x & 63;
+    const long ngroups = (long)B * P * heads;
+    long gid = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * GW + lane / CL;
+    const bool valid = gid < ngroups;
+    if (!valid) gid = ngroups - 1;            // keep every lane alive for the DPP reductions
+    const int cl = lane % CL;
+    const int h = (int)(gid % heads);
+    const long bp = gid / heads;
+    const long b = bp / P, p = bp % P;
+    const int inner = heads * DH;
+    const long row0 = b * F * P + p;          // frame f lives at row0 + f*P
+    const int col = h * DH + cl * EPL;
+
+    float k[FMAX][EPL], vv[FMAX][EPL];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f) {
+        if (f < F) {
+            const long m = row0 + (long)f * P;
+            loadE<EPL>(qk + m * 2 * inner + inner + col, k[f]);
+            loadE<EPL>(v + m * inner + col, vv[f]);
+        }
+    }
+    float qn[EPL];
+    loadE<EPL>(qk + row0 * 2 * inner + col, qn);
+#pragma unroll
+    for (int i = 0; i < FMAX; ++i) {
+        if (i < F) {
+            float q[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) q[e] = qn[e];
+            if (i + 1 < F) loadE<EPL>(qk + (row0 + (long)(i + 1) * P) * 2 * inner + col, qn);     // one frame ahead
+            float s[FMAX];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) {
+                    s[j] = cluster_sum<CL>(dotE<EPL>(q, k[j])) * scale;
+                    mx = fmaxf(mx, s[j]);
+                }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) { s[j] = __expf(s[j] - mx); sum += s[j]; }
+            }
+            const float inv = 1.0f / sum;
+            float o[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) {
+                    const float pj = s[j] * inv;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) o[e] += pj * vv[j][e];
+                }
+            }
+            if (valid) {
+                const long m = row0 + (long)i * P;
+                storeE<EPL>(out + m * inner + col, o);
+            }
+        }
+    }
+}
+
+// backward: dqk [B*F*P][2*inner] (dq | dk), dv [B*F*P][inner]
+// HOLD: every q / dO row in registers (F <= 9); otherwise they are fetched one frame ahead of their use
+template <typename T, int DH, int FMAX, int EPL, bool HOLD = false>
+__global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ qk, const T* __restrict__ v,
+                                                        const T* __restrict__ dout, T* __restrict__ dqk,
+                                                        T* __restrict__ dv, int B, int F, int P, int heads,
+                                                        float scale) {
+    constexpr int CL = DH / EPL, GW = 64 / CL;
+    const int lane = threadIdx.x & 63;
+    const long ngroups = (long)B * P * heads;
+    long gid = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * GW + lane / CL;
+    const bool valid = gid < ngroups;
+    if (!valid) gid = ngroups - 1;
+    const int cl = lane % CL;
+    const int h = (int)(gid % heads);
+    const long bp = gid / heads;
+    const long b = bp / P, p = bp % P;
+    const int inner = heads * DH;
+    const long row0 = b * F * P + p;
+    const int col = h * DH + cl * EPL;
+
+    float k[FMAX][EPL], vv[FMAX][EPL], dk[FMAX][EPL], dvv[FMAX][EPL];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f) {
+        if (f < F) {
+            const long m = row0 + (long)f * P;
+            loadE<EPL>(qk + m * 2 * inner + inner + col, k[f]);
+            loadE<EPL>(v + m * inner + col, vv[f]);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { dk[f][e] = 0.f; dvv[f][e] = 0.f; }
+        }
+    }
+    constexpr int NH = HOLD ? FMAX : 1;
+    float qa[NH][EPL], da[NH][EPL];
+    float qn[EPL], don[EPL];
+    if (HOLD) {
+#pragma unroll
+        for (int f = 0; f < NH; ++f) {
+            if (f < F) {
+                loadE<EPL>(qk + (row0 + (long)f * P) * 2 * inner + col, qa[f]);
+                loadE<EPL>(dout + (row0 + (long)f * P) * inner + col, da[f]);
+            }
+        }
+    } else {
+        loadE<EPL>(qk + row0 * 2 * inner + col, qn);
+        loadE<EPL>(dout + row0 * inner + col, don);
+    }
+#pragma unroll
+    for (int i = 0; i < FMAX; ++i) {
+        if (i < F) {
+            const long m = row0 + (long)i * P;
+            float q[EPL], dO[EPL];
+            if (HOLD) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { q[e] = qa[HOLD ? i : 0][e]; dO[e] = da[HOLD ? i : 0][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) { q[e] = qn[e]; dO[e] = don[e]; }
+                if (i + 1 < F) {                                               // one frame ahead
+                    loadE<EPL>(qk + (m + P) * 2 * inner + col, qn);
+                    loadE<EPL>(dout + (m + P) * inner + col, don);
+                }
+            }
+            // probabilities are recomputed exactly as the forward computes them (max, exp, sum,
+            // divide): a saved log-sum-exp would leave sum(p) != 1 by eps*|lse| and that error is
+            // amplified in p*(dp - delta) when the softmax is peaked.
+            float pr[FMAX], dp[FMAX];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) {
+                    pr[j] = cluster_sum<CL>(dotE<EPL>(q, k[j])) * scale;
+                    mx = fmaxf(mx, pr[j]);
+                    dp[j] = cluster_sum<CL>(dotE<EPL>(dO, vv[j]));
+                }
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) { pr[j] = __expf(pr[j] - mx); sum += pr[j]; }
+            }
+            const float inv = 1.0f / sum;
+            float delta = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) { pr[j] *= inv; delta += pr[j] * dp[j]; }
+            }
+            float dq[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dq[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < FMAX; ++j) {
+                if (j < F) {
+                    const float ds = pr[j] * (dp[j] - delta) * scale;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        dq[e] += ds * k[j][e];
+                        dk[j][e] += ds * q[e];
+                        dvv[j][e] += pr[j] * dO[e];
+                    }
+                }
+            }
+            if (valid) storeE<EPL>(dqk + m * 2 * inner + col, dq);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) {
+            if (f < F) {
+                const long m = row0 + (long)f * P;
+                storeE<EPL>(dqk + m * 2 * inner + inner + col, dk[f]);
+                storeE<EPL>(dv + m * inner + col, dvv[f]);
+            }
+        }
+    }
+}
+
+#define DISPATCH_TATTN(KERNEL, KERNEL2, ...)                                                             \
     do {                                                                                                 \
         const long ngroups = (long)B * P * heads;                                                        \
-        const int cl = dh / 4, gw = 64 / cl;                                                             \
+        const int epl = F <= 9 ? 4 : 2;                                                                  \
+        const int gw = 64 / (dh / epl);                                                                  \
         const long blocks = (ngroups + 4 * gw - 1) / (4 * gw);                                           \
         dim3 grid((unsigned)blocks), block(256);                                                         \
-        if (dh == 64 && F <= 9) hipLaunchKernelGGL((KERNEL<T, 64, 9>), grid, block, 0, stream, __VA_ARGS__);        \
-        else if (dh == 64 && F <= 17) hipLaunchKernelGGL((KERNEL<T, 64, 17>), grid, block, 0, stream, __VA_ARGS__); \
-        else if (dh == 32 && F <= 9) hipLaunchKernelGGL((KERNEL<T, 32, 9>), grid, block, 0, stream, __VA_ARGS__);   \
-        else if (dh == 32 && F <= 17) hipLaunchKernelGGL((KERNEL<T, 32, 17>), grid, block, 0, stream, __VA_ARGS__); \
+        if (dh == 64 && F <= 9) hipLaunchKernelGGL((KERNEL<T, 64, 9>), grid, block, 0, stream, __VA_ARGS__);           \
+        else if (dh == 64 && F <= 17) hipLaunchKernelGGL((KERNEL2<T, 64, 17, 2>), grid, block, 0, stream, __VA_ARGS__); \
+        else if (dh == 32 && F <= 9) hipLaunchKernelGGL((KERNEL<T, 32, 9>), grid, block, 0, stream, __VA_ARGS__);      \
+        else if (dh == 32 && F <= 17) hipLaunchKernelGGL((KERNEL2<T, 32, 17, 2>), grid, block, 0, stream, __VA_ARGS__); \
         else return ISTVT_ERR_SHAPE;                                                                     \
     } while (0)
 
 extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, int B, int F, int P, int heads,
                                        int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P, heads, scale));
+    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, tattn_fwd2_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P,
+                                         heads, scale));
     return istvt_check_launch();
 }
 
 extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int B,
                                        int F, int P, int heads, int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, (const T*)qk, (const T*)v, (const T*)dout, (T*)dqk, (T*)dv,
-                                         B, F, P, heads, scale));
+    DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, tattn_bwd2_kernel, (const T*)qk, (const T*)v, (const T*)dout,
+                                         (T*)dqk, (T*)dv, B, F, P, heads, scale));
     return istvt_check_launch();
 }
