@@ -68,6 +68,25 @@ __device__ __forceinline__ typename Mma<T>::frag acc_frag(const f32x4& lo, const
     return f;
 }
 
+// ---- fp8 (OCP e4m3) operands for the attention MFMAs (BASELINE config 5): the bf16 fragments are converted in
+// registers and fed to v_mfma_f32_16x16x32_fp8_fp8, whose 8-bytes-per-lane K = 32 operand layout is the bf16 one
+__device__ __forceinline__ long pack_fp8(const float (&v)[8]) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long to_fp8(const bf16x8& f) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)f[i];
+    return pack_fp8(v);
+}
+__device__ __forceinline__ long to_fp8(const f32frag& f) { return pack_fp8(f.v); }
+__device__ __forceinline__ void mma8(f32x4& c, long a, long b) { c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+constexpr float P8_SCALE = 256.f;          // probabilities (<= 1) are scaled into e4m3's normal range before conversion
+
 __device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same r)
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -81,7 +100,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // U = query tiles (of 16) per wavefront, 128 / (16 U) wavefronts per workgroup.  U = 1 (8 wavefronts) halves the
 // registers of a wavefront: 4 instead of 2 wavefronts per SIMD, whose softmax (VALU) and MFMA phases then overlap and
 // whose staging latencies hide each other (the kernel is bound by neither pipe: it waits).
-template <typename T, int DH, int U>
+template <typename T, int DH, int U, bool FP8 = false>
 __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         float* __restrict__ lse, int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
@@ -101,10 +120,14 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
     const float c = scale * LOG2E;
 
     typename Mma<T>::frag qf[U][KS];
+    long q8[U][KS];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[u][ks] = row_frag<T>(qp, ld, q0 + 16 * u + r, P, 32 * ks + 8 * g);
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[u][ks] = row_frag<T>(qp, ld, q0 + 16 * u + r, P, 32 * ks + 8 * g);
+            if constexpr (FP8) q8[u][ks] = to_fp8(qf[u][ks]);
+        }
 
     f32x4 o[DT][U];
     float m_run[U], l_run[U];
@@ -130,8 +153,14 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     typename Mma<T>::frag kf = frag_load(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
+                    if constexpr (FP8) {
+                        const long k8 = to_fp8(kf);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) Mma<T>::mma(s[t][u], kf, qf[u][ks]);
+                        for (int u = 0; u < U; ++u) mma8(s[t][u], k8, q8[u][ks]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) Mma<T>::mma(s[t][u], kf, qf[u][ks]);
+                    }
                 }
             }
         }
@@ -171,14 +200,30 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss < P) {
                 typename Mma<T>::frag pf[U];
+                long p8[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) pf[u] = acc_frag<T>(s[2 * ss][u], s[2 * ss + 1][u]);
+                for (int u = 0; u < U; ++u) {
+                    if constexpr (FP8) {
+                        const f32x4 &lo = s[2 * ss][u], &hi = s[2 * ss + 1][u];
+                        const float pv[8] = {lo[0] * P8_SCALE, lo[1] * P8_SCALE, lo[2] * P8_SCALE, lo[3] * P8_SCALE,
+                                             hi[0] * P8_SCALE, hi[1] * P8_SCALE, hi[2] * P8_SCALE, hi[3] * P8_SCALE};
+                        p8[u] = pack_fp8(pv);
+                    } else {
+                        pf[u] = acc_frag<T>(s[2 * ss][u], s[2 * ss + 1][u]);
+                    }
+                }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     typename Mma<T>::frag vf =
                         frag_load_tr(Vimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                    if constexpr (FP8) {
+                        const long v8 = to_fp8(vf);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) Mma<T>::mma(o[dt][u], vf, pf[u]);
+                        for (int u = 0; u < U; ++u) mma8(o[dt][u], v8, p8[u]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) Mma<T>::mma(o[dt][u], vf, pf[u]);
+                    }
                 }
             }
         }
@@ -189,10 +234,11 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
         const int q = q0 + 16 * u + r;
         if (q >= P) continue;
         const float inv = 1.0f / l_run[u];
+        const float oinv = FP8 ? inv * (1.0f / P8_SCALE) : inv;
         T* op = out + ((long)bf * P + q) * inner + h * DH;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            float v[4] = {o[dt][u][0] * inv, o[dt][u][1] * inv, o[dt][u][2] * inv, o[dt][u][3] * inv};
+            float v[4] = {o[dt][u][0] * oinv, o[dt][u][1] * oinv, o[dt][u][2] * oinv, o[dt][u][3] * oinv};
             store4(op + 16 * dt + 4 * g, v);
         }
         if (g == 0) {
@@ -207,7 +253,7 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
 
 // ------------------------------------------------------------------------------------------
 // backward part 1: delta = rowsum(dO o O), dQ
-template <typename T, int DH, int U>
+template <typename T, int DH, int U, bool FP8 = false>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv, int P,
@@ -231,6 +277,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
     const float c = scale * LOG2E;
 
     typename Mma<T>::frag qf[U][KS], dof[U][KS];
+    long q8[U][KS];
     float lq[U], li[U], dl[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -239,6 +286,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             qf[u][ks] = row_frag<T>(qp, ld, q, P, 32 * ks + 8 * g);
+            if constexpr (FP8) q8[u][ks] = to_fp8(qf[u][ks]);        // S is recomputed exactly as the forward computed it
             dof[u][ks] = row_frag<T>(dop, inner, q, P, 32 * ks + 8 * g);
             if (q < P) {
                 float a[8], b[8];
@@ -281,7 +329,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
                     typename Mma<T>::frag vf = frag_load(Vimg + krow * LDI + 32 * ks + 8 * g);
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        Mma<T>::mma(s[tt][u], kf, qf[u][ks]);
+                        if constexpr (FP8) mma8(s[tt][u], to_fp8(kf), q8[u][ks]);
+                        else Mma<T>::mma(s[tt][u], kf, qf[u][ks]);
                         Mma<T>::mma(dp[tt][u], vf, dof[u][ks]);
                     }
                 }
@@ -321,7 +370,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
 
 // ------------------------------------------------------------------------------------------
 // backward part 2: dK, dV.  Wave owns 32 keys; queries stream through LDS.
-template <typename T, int DH, int U>
+template <typename T, int DH, int U, bool FP8 = false>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
@@ -345,11 +394,13 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
     const float c = scale * LOG2E;
 
     typename Mma<T>::frag kf[U][KS], vf[U][KS];
+    long k8[U][KS];
 #pragma unroll
     for (int kt = 0; kt < U; ++kt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kf[kt][ks] = row_frag<T>(kp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
+            if constexpr (FP8) k8[kt][ks] = to_fp8(kf[kt][ks]);
             vf[kt][ks] = row_frag<T>(vp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
         }
     f32x4 dk[DT][U], dv[DT][U];
@@ -387,7 +438,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                     typename Mma<T>::frag da = frag_load(Dimg + qrow * LDI + 32 * ks + 8 * g);
 #pragma unroll
                     for (int kt = 0; kt < U; ++kt) {
-                        Mma<T>::mma(s[tt][kt], qa, kf[kt][ks]);
+                        if constexpr (FP8) mma8(s[tt][kt], to_fp8(qa), k8[kt][ks]);
+                        else Mma<T>::mma(s[tt][kt], qa, kf[kt][ks]);
                         Mma<T>::mma(dp[tt][kt], da, vf[kt][ks]);
                     }
                 }
@@ -487,5 +539,33 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, const void* out, const vo
         hipLaunchKernelGGL((sattn_bwd_dkv_kernel<T, DH, 2>), grid, block, 0, stream, (const T*)qkv, (const T*)dout, lse,
                            (const float*)delta, (T*)dqkv, P, heads, scale);
     }));
+    return istvt_check_launch();
+}
+
+// ---- fp8 variant (bfloat16 storage only): Q, K, V and the probabilities enter the attention MFMAs as OCP e4m3
+// (v_mfma_f32_16x16x32_fp8_fp8); softmax, statistics, accumulation and every other product stay as above.  The
+// backward recomputes S with the same fp8 operands, so the saved (max, 1/sum) match its probabilities.
+extern "C" int istvt_attn_spatial_fwd_fp8(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh,
+                                          float scale, int dtype, hipStream_t stream) {
+    if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
+    dim3 grid((P + 127) / 128, BF * heads);
+    DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream,
+                                       (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse,
+                                          float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale,
+                                          int dtype, hipStream_t stream) {
+    if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
+    dim3 grid((P + 127) / 128, BF * heads);
+    DISPATCH_DH(dh, {
+        hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+        hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
+                           (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+    });
     return istvt_check_launch();
 }

@@ -155,17 +155,18 @@ class SpatialAttnFn(Function):
     """softmax(q k^T / sqrt(d)) v per (frame, head) on packed qkv [BF*P, 3*inner] (module.py:84-91)."""
 
     @staticmethod
-    def forward(ctx, qkv, BF, P, heads, dh):
-        out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh)
+    def forward(ctx, qkv, BF, P, heads, dh, fp8=False):
+        out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh, fp8=fp8)
         ctx.save_for_backward(qkv, out, lse)
         ctx.geom = (BF, P, heads, dh)
+        ctx.fp8 = fp8
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        return ops.attn_spatial_bwd(qkv, out, dout, lse, *ctx.geom), None, None, None, None
+        return ops.attn_spatial_bwd(qkv, out, dout, lse, *ctx.geom, fp8=ctx.fp8), None, None, None, None, None
 
 
 class TemporalAttnFn(Function):

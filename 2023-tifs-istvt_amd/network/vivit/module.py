@@ -87,6 +87,7 @@ class SpatialOnlyAttention(nn.Module):
         self.dim_head = dim_head
         self.scale = dim_head ** -0.5
         self.hw = hw
+        self.attn_fp8 = False           # fp8 (e4m3) operands in the attention MFMAs (bfloat16 activations only)
         self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
         self.to_out = nn.Sequential(
             nn.Linear(inner_dim, dim),
@@ -99,7 +100,7 @@ class SpatialOnlyAttention(nn.Module):
         frames = _frames(n, hw, 'SpatialOnlyAttention')
         x2 = x.reshape(b * n, -1)
         qkv = Fn.LinearFn.apply(x2, self.to_qkv.weight, None, None)
-        out = Fn.SpatialAttnFn.apply(qkv, b * frames, hw, self.heads, self.dim_head)
+        out = Fn.SpatialAttnFn.apply(qkv, b * frames, hw, self.heads, self.dim_head, self.attn_fp8)
         proj = self.to_out[0]
         plain = self.to_out[1].p == 0.0 or not self.training
         r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None

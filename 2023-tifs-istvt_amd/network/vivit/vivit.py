@@ -84,13 +84,23 @@ class XceptionVidTr(nn.Module):
     geometry it hard-codes."""
 
     def __init__(self, *, num_frames=6, grid=19, depth=12, dim=728, heads=8, dim_head=64, scale_dim=4,
-                 num_classes=1, compute_dtype=torch.float32):
+                 num_classes=1, compute_dtype=torch.float32, attn_fp8=False):
         super(XceptionVidTr, self).__init__()
         from ..models import model_selection
         self.xcep = model_selection(modelname='xception', num_out_classes=2, dropout=0.5, batch_size=1)
         self.vit = DSTTr(grid, 1, num_classes, num_frames, dim=dim, depth=depth, heads=heads, dim_head=dim_head,
                          scale_dim=scale_dim, compute_dtype=compute_dtype)
         self.compute_dtype = compute_dtype
+        self.set_attn_fp8(attn_fp8)
+
+    def set_attn_fp8(self, on=True):
+        """fp8 (OCP e4m3) operands in the spatial-attention MFMAs (BASELINE.json configs[4]); needs bfloat16 compute."""
+        if on and self.compute_dtype != torch.bfloat16:
+            raise ValueError('attn_fp8 needs compute_dtype=torch.bfloat16')
+        for m in self.modules():
+            if isinstance(m, SpatialOnlyAttention):
+                m.attn_fp8 = bool(on)
+        return self
 
     def set_compute_dtype(self, dtype):
         self.compute_dtype = dtype

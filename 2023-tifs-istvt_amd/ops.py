@@ -394,28 +394,32 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
 
 
 # ------------------------------------------------------------------------------------------
-def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int):
+def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int, fp8: bool = False):
     qkv = _c(_req(qkv))
     inner = heads * dh
     if qkv.numel() != BF * P * 3 * inner:
         raise RuntimeError('attn_spatial: qkv %s is not (%d*%d, 3*%d)' % (tuple(qkv.shape), BF, P, inner))
     out = torch.empty((BF * P, inner), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((BF * P, heads, 2), dtype=torch.float32, device=qkv.device)   # (row max [log2], 1/rowsum)
+    if fp8 and qkv.dtype != torch.bfloat16:
+        raise TypeError('the fp8 attention path needs bfloat16 activations')
+    fn = _lib.lib().istvt_attn_spatial_fwd_fp8 if fp8 else _lib.lib().istvt_attn_spatial_fwd
     with prof('attn_spatial_fwd', 4 * BF * P * inner * qkv.element_size(), 4.0 * BF * heads * P * P * dh):
-        _lib.check(_lib.lib().istvt_attn_spatial_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh,
-                                                     dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_fwd')
+        _lib.check(fn(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh, dh ** -0.5, dtype_code(qkv),
+                      _stream()), 'istvt_attn_spatial_fwd')
     return out, lse
 
 
-def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: int, P: int, heads: int, dh: int) -> Tensor:
+def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: int, P: int, heads: int, dh: int,
+                     fp8: bool = False) -> Tensor:
     dout = _c(_req(dout))
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
     inner = heads * dh
+    fn = _lib.lib().istvt_attn_spatial_bwd_fp8 if fp8 else _lib.lib().istvt_attn_spatial_bwd
     with prof('attn_spatial_bwd', 8 * BF * P * inner * qkv.element_size(), 10.0 * BF * heads * P * P * dh):
-        _lib.check(_lib.lib().istvt_attn_spatial_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                                     delta.data_ptr(), dqkv.data_ptr(), BF, P, heads, dh, dh ** -0.5,
-                                                     dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
+        _lib.check(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
+                      BF, P, heads, dh, dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
     return dqkv
 
 

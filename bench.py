@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--depth', type=int, default=12)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--attn-fp8', action='store_true', help='fp8 (e4m3) operands in the spatial-attention MFMAs (configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     return ap.parse_args()
@@ -98,7 +99,8 @@ def main():
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     grid = stem_mod.out_side(a.size)
     torch.manual_seed(0)                       # identical init on every rank (+ broadcast below)
-    model = XceptionVidTr(num_frames=a.frames, grid=grid, depth=a.depth, compute_dtype=dtype).to(dev).train()
+    model = XceptionVidTr(num_frames=a.frames, grid=grid, depth=a.depth, compute_dtype=dtype,
+                          attn_fp8=a.attn_fp8).to(dev).train()
     parallel.broadcast_parameters(model)
     live = [p for _, p in parallel.live_named_parameters(model)]
     bucket = parallel.GradBucket(live, fuse_accumulate=True)
@@ -200,7 +202,7 @@ def main():
             'config': {'workload': 'C2: B=%d/GPU T=%d %dx%d full ISTVT (Xception stem + %d-layer DSTTr) train step '
                                    '(fwd+bwd+grad all-reduce+SGD), random-init weights' % (a.batch, a.frames, a.size, a.size, a.depth),
                        'global_batch': world * a.batch, 'frames': a.frames, 'size': a.size, 'depth': a.depth,
-                       'parallelism': 'dp%d' % world, 'loss': round(loss_val, 5)},
+                       'parallelism': 'dp%d' % world, 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
         }
         gf = GF_PER_CLIP_FWD_BWD.get(a.frames) if (a.size == 224 and a.depth == 12) else None
         if gf:

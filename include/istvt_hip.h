@@ -77,6 +77,14 @@ int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P
 int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta_scratch,
                            void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
                            istvt_stream_t stream);
+/* fp8 variant of the two entry points above (BASELINE.json configs[4]; bfloat16 storage only): Q, K, V and the
+ * softmax probabilities enter the attention MFMAs as OCP e4m3 (v_mfma_f32_16x16x32_fp8_fp8); softmax, statistics,
+ * accumulation and the remaining backward products are unchanged.  Same arguments. */
+int istvt_attn_spatial_fwd_fp8(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh, float scale,
+                               int dtype, istvt_stream_t stream);
+int istvt_attn_spatial_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                               void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
+                               istvt_stream_t stream);
 
 /* ---- temporal attention (TemporalResidualAttention.forward core, module.py:197-205) --------
  * qk [B*F*P][2*heads*dh] (q|k), v/out [B*F*P][heads*dh], rows (b,f,p); F <= 17. */

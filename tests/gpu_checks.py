@@ -196,6 +196,29 @@ def attn_spatial(dtype, BF=3, P=197, heads=8, dh=64):
     return max(e_f, e_b), TOL[dtype]
 
 
+def attn_spatial_fp8(BF=3, P=197, heads=8, dh=64):
+    """fp8 (e4m3) operands in the attention MFMAs (BASELINE configs[4]): forward and input gradients against the fp64
+    attention of the SAME bf16 inputs.  The tolerance is the fp8 quantisation: 3 mantissa bits on q, k, v and on the
+    (256x scaled) probabilities -> a few percent per element, sqrt-averaged over 64 / 197 terms."""
+    dtype = torch.bfloat16
+    inner = heads * dh
+    qkv = rnd((BF * P, 3 * inner), dtype, 1)
+    out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh, fp8=True)
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = (t.view(BF, P, heads, dh).transpose(1, 2) for t in qd.chunk(3, dim=-1))
+    ref = _attn_ref(q, k, v).transpose(1, 2).reshape(BF * P, inner)
+    dout = rnd((BF * P, inner), dtype, 2)
+    ref.backward(dout.double())
+    dqkv = ops.attn_spatial_bwd(qkv, out, dout, lse, BF, P, heads, dh, fp8=True)
+    e_f = relerr(out, ref)
+    e_b = max(relerr(a, b) for a, b in zip(dqkv.chunk(3, dim=-1), qd.grad.chunk(3, dim=-1)))
+    # and against the bf16-operand kernel on the same inputs: the delta the config asks to report
+    out16, _ = ops.attn_spatial_fwd(qkv, BF, P, heads, dh)
+    print('attn_spatial_fp8: forward rel err vs fp64 %.3e, backward %.3e, forward delta vs bf16 kernel %.3e'
+          % (e_f, e_b, relerr(out, out16)))
+    return max(e_f, e_b), 8e-2
+
+
 def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64):
     inner = heads * dh
     M = B * F * P
@@ -255,7 +278,8 @@ def cast_transpose(R=1000, C=728):
 
 def all_checks():
     """-> list of (name, callable)"""
-    out = [('cast_transpose', cast_transpose), ('cast_transpose_tail', lambda: cast_transpose(520, 1544))]
+    out = [('cast_transpose', cast_transpose), ('cast_transpose_tail', lambda: cast_transpose(520, 1544)),
+           ('attn_spatial_fp8_P197', attn_spatial_fp8), ('attn_spatial_fp8_P37', lambda: attn_spatial_fp8(4, 37, 8, 64))]
     for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
         for mode in ('fwd', 'dgrad', 'wgrad'):
             out.append(('gemm_exact_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode)))

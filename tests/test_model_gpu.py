@@ -154,6 +154,30 @@ def test_bf16_mode_tracks_fp32():
     assert all(torch.isfinite(q.grad).all() for q in m16.parameters() if q.grad is not None)
 
 
+def test_fp8_attention_tracks_bf16():
+    """BASELINE.json configs[4]: fp8 (e4m3) Q/K/V/P operands in the spatial-attention MFMAs, everything else bf16.
+    Reports the logit delta against the bf16 run on identical inputs and weights; tolerance 5e-2 of the logit scale
+    (measured ~1e-2 at random init, depth 2)."""
+    R, p, x, labels, grid = _oracle_case(2, 8, 224, 2)
+    m16 = _hip_model(p, 8, grid, 2, dtype=torch.bfloat16)
+    with torch.no_grad():
+        y16 = m16(x.cuda())
+    m8 = _hip_model(p, 8, grid, 2, dtype=torch.bfloat16).set_attn_fp8(True)
+    y8 = m8(x.cuda())
+    torch.nn.functional.binary_cross_entropy_with_logits(y8.view(-1), labels.cuda()).backward()
+    m16b = _hip_model(p, 8, grid, 2, dtype=torch.bfloat16)
+    torch.nn.functional.binary_cross_entropy_with_logits(m16b(x.cuda()).view(-1), labels.cuda()).backward()
+    d_abs = float((y8.detach() - y16).abs().max())
+    d_rel = d_abs / float(y16.abs().max().clamp_min(1e-3))
+    g8 = m8.vit.transformer.layers[0][1].fn.to_qkv.weight.grad
+    g16 = m16b.vit.transformer.layers[0][1].fn.to_qkv.weight.grad
+    g_rel = float((g8 - g16).norm() / g16.norm())
+    print('fp8 attention vs bf16: max |dlogit| %.3e (%.3e of max |logit|); to_qkv grad rel diff %.3e' % (d_abs, d_rel, g_rel))
+    assert d_rel < 5e-2
+    assert g_rel < 0.25
+    assert all(torch.isfinite(q.grad).all() for q in m8.parameters() if q.grad is not None)
+
+
 def test_fused_bucket_accumulation_matches_autograd():
     """GradBucket(fuse_accumulate=True): kernels add straight into the flat bucket; same gradients."""
     import istvt_pkg
