@@ -18,6 +18,8 @@
 // qk : [B*F*P][2*inner]  (q | k), v : [B*F*P][inner], out : [B*F*P][inner], rows ordered (b,f,p).
 // Nothing is saved for backward: the F x F probabilities are recomputed from q,k.
 #include "common.h"
+#include <cstdlib>
+#include "attn_temporal_mfma.h"
 
 template <int CL> __device__ __forceinline__ float cluster_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
@@ -431,6 +433,14 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
 extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, int B, int F, int P, int heads,
                                        int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
+    if (use_mfma && dtype == DT_BF16 && F <= 32 && (dh == 64 || dh == 32)) {     // one wavefront per (b, p, h), MFMA tiles
+        const long nprob = (long)B * P * heads;
+        dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
+        if (dh == 64) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<64>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale);
+        else hipLaunchKernelGGL((tattn_mfma_fwd_kernel<32>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale);
+        return istvt_check_launch();
+    }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, tattn_fwd2_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P,
                                          heads, scale));
     return istvt_check_launch();
@@ -439,6 +449,16 @@ extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out,
 extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int B,
                                        int F, int P, int heads, int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
+    // measured at C2 / C4 (tools/tattn_bench.py): F = 9 lane-cluster 170 us vs MFMA 203 us (its three 32-row LDS images
+    // allow 8 wavefronts per CU); F = 17 850 us vs 336 us
+    if (use_mfma && dtype == DT_BF16 && F > 9 && F <= 32 && (dh == 64 || dh == 32)) {
+        const long nprob = (long)B * P * heads;
+        dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
+        if (dh == 64) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<64>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale);
+        else hipLaunchKernelGGL((tattn_mfma_bwd_kernel<32>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale);
+        return istvt_check_launch();
+    }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, tattn_bwd2_kernel, (const T*)qk, (const T*)v, (const T*)dout,
                                          (T*)dqk, (T*)dv, B, F, P, heads, scale));
     return istvt_check_launch();

@@ -1,0 +1,300 @@
+// MFMA formulation of the per-position temporal attention for bfloat16 (included by attn_temporal.hip).
+//
+// The lane-cluster kernels of attn_temporal.hip spend ~28 vector instructions per (query frame, key frame) pair and
+// are VALU-bound, badly so at F = 17 (T = 16: 1 TB/s).  Here ONE WAVEFRONT owns one (clip b, position p, head h):
+// F <= 32 frames are padded to two 16-row MFMA tiles and every product is a v_mfma_f32_16x16x32_bf16, exactly the
+// dataflow of the spatial kernels (attn_spatial.hip) with a 32-row "chunk":
+//   forward   S^T = K Q^T (keys on accumulator rows, queries on lanes) -> softmax over keys in registers ->
+//             O^T = V^T P^T with the S^T accumulators as the B operand and V read transposed from LDS
+//   backward  part 1 (per query tile): S^T, dP^T = V dO^T, p, delta = sum_j p dp, dS^T -> dQ^T = K^T dS^T;
+//                    (max, 1/sum, delta) per query go to a 3 x 32 LDS table
+//             part 2 (per key tile):   S = Q K^T, dP = dO V^T (queries on accumulator rows, keys on lanes),
+//                    p, dS from the table -> dV^T = dO^T P, dK^T = Q^T dS
+// Rows of one problem are F rows P apart (row stride P * ld), so every operand fragment that is not transposed is
+// loaded straight from global memory in MFMA layout (16 bytes per lane, one row per lane); the operands that are
+// read TRANSPOSED (V forward; K, Q, dO backward) are staged through a wave-private LDS image of 32 rows.
+// No workgroup barrier anywhere: a wavefront's LDS operations execute in order.
+#pragma once
+
+namespace tmf {
+constexpr int ROWS = 32, IPAD = 8;
+#define TM_LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (bf16_t)0.0f;
+    return f;
+}
+// 8 consecutive elements of row `row` (rows >= nrows read as zeros); rstride = elements between rows
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* __restrict__ src, long rstride, int row, int nrows, int col) {
+    if (row < nrows) return *reinterpret_cast<const bf16x8*>(src + (long)row * rstride + col);
+    return zero8();
+}
+__device__ __forceinline__ bf16x8 acc_frag(const f32x4& lo, const f32x4& hi) {
+    bf16x8 f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = (bf16_t)lo[i]; f[4 + i] = (bf16_t)hi[i]; }
+    return f;
+}
+__device__ __forceinline__ void mma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same r)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// rows 0..31 x DH of a strided matrix -> wave-private LDS image [32][DH + IPAD]; rows >= nrows are zero-filled
+template <int DH>
+__device__ __forceinline__ void stage32(bf16_t* img, const bf16_t* __restrict__ src, long rstride, int nrows, int lane) {
+    constexpr int LDI = DH + IPAD, VPR = DH / 8, RPI = 64 / VPR;      // rows per wave-instruction
+#pragma unroll
+    for (int it = 0; it < ROWS / RPI; ++it) {
+        const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
+        *reinterpret_cast<bf16x8*>(img + row * LDI + col) = row_frag(src, rstride, row, nrows, col);
+    }
+}
+}  // namespace tmf
+
+template <int DH>
+__global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
+                                                             bf16_t* __restrict__ out, int B, int F, int P, int heads,
+                                                             float scale) {
+    constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4][tmf::ROWS * LDI];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
+    const long prob = (long)blockIdx.x * 4 + wave;
+    if (prob >= (long)B * P * heads) return;              // no workgroup-level synchronisation below
+    const int h = (int)(prob % heads);
+    const long bp = prob / heads, b = bp / P, p = bp % P;
+    const int inner = heads * DH;
+    const long row0 = b * F * P + p;
+    const long sq = (long)P * 2 * inner, sv = (long)P * inner;
+    const bf16_t* qp = qk + row0 * 2 * inner + h * DH;
+    const bf16_t* kp = qp + inner;
+    const bf16_t* vp = v + row0 * inner + h * DH;
+    bf16_t* op = out + row0 * inner + h * DH;
+    bf16_t* Vimg = smem[wave];
+    const float c = scale * TM_LOG2E;
+
+    tmf::stage32<DH>(Vimg, vp, sv, F, lane);
+    bf16x8 kf[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
+    tmf::wave_lds_fence();
+
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (16 * u >= F) break;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = tmf::row_frag(qp, sq, 16 * u + r, F, 32 * ks + 8 * g);
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) tmf::mma(s[t], kf[t][ks], qf[ks]);
+        }
+        // softmax over keys: lane owns query r, keys 16t + 4g + j
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = (16 * t + 4 * g + j) < F ? s[t][j] * c : -INFINITY;
+                s[t][j] = z;
+                mx = fmaxf(mx, z);
+            }
+        mx = tmf::group_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = fast_exp2(s[t][j] - mx);
+                s[t][j] = pv;
+                sum += pv;
+            }
+        sum = tmf::group_sum(sum);
+        const float inv = 1.0f / sum;
+        const bf16x8 pf = tmf::acc_frag(s[0], s[1]);
+        const int q = 16 * u + r;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 o = f32x4{0, 0, 0, 0};
+            tmf::mma(o, frag_load_tr(Vimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), pf);
+            if (q < F) {
+                float ov[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+                store4(op + (long)q * sv + 16 * dt + 4 * g, ov);
+            }
+        }
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
+                                                             const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqk,
+                                                             bf16_t* __restrict__ dv, int B, int F, int P, int heads,
+                                                             float scale) {
+    constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * tmf::ROWS * LDI];
+    __shared__ __attribute__((aligned(16))) float stat[4][3][tmf::ROWS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
+    const long prob = (long)blockIdx.x * 4 + wave;
+    if (prob >= (long)B * P * heads) return;
+    const int h = (int)(prob % heads);
+    const long bp = prob / heads, b = bp / P, p = bp % P;
+    const int inner = heads * DH;
+    const long row0 = b * F * P + p;
+    const long sq = (long)P * 2 * inner, sv = (long)P * inner;
+    const bf16_t* qp = qk + row0 * 2 * inner + h * DH;
+    const bf16_t* kp = qp + inner;
+    const bf16_t* vp = v + row0 * inner + h * DH;
+    const bf16_t* dop = dout + row0 * inner + h * DH;
+    bf16_t* dqp = dqk + row0 * 2 * inner + h * DH;
+    bf16_t* dkp = dqp + inner;
+    bf16_t* dvp = dv + row0 * inner + h * DH;
+    bf16_t* Qimg = smem[wave];
+    bf16_t* Kimg = Qimg + tmf::ROWS * LDI;
+    bf16_t* Dimg = Kimg + tmf::ROWS * LDI;
+    float (*st)[tmf::ROWS] = stat[wave];
+    const float c = scale * TM_LOG2E;
+
+    tmf::stage32<DH>(Qimg, qp, sq, F, lane);
+    tmf::stage32<DH>(Kimg, kp, sq, F, lane);
+    tmf::stage32<DH>(Dimg, dop, sv, F, lane);
+    // operands used un-transposed, straight from global memory in fragment layout (row 16t + r, columns 32ks + 8g)
+    bf16x8 kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
+            vf[t][ks] = tmf::row_frag(vp, sv, 16 * t + r, F, 32 * ks + 8 * g);
+        }
+    tmf::wave_lds_fence();
+
+    // ---- part 1: per query tile u -- S^T, dP^T (keys on rows, queries on lanes), statistics, dQ
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (16 * u >= F) break;
+        const int q = 16 * u + r;
+        bf16x8 qf[KS], dof[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = tmf::row_frag(qp, sq, q, F, 32 * ks + 8 * g);
+            dof[ks] = tmf::row_frag(dop, sv, q, F, 32 * ks + 8 * g);
+        }
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = f32x4{0, 0, 0, 0}; dp[t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                tmf::mma(s[t], kf[t][ks], qf[ks]);
+                tmf::mma(dp[t], vf[t][ks], dof[ks]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = (16 * t + 4 * g + j) < F ? s[t][j] * c : -INFINITY;
+                s[t][j] = z;
+                mx = fmaxf(mx, z);
+            }
+        mx = tmf::group_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = fast_exp2(s[t][j] - mx);
+                s[t][j] = pv;
+                sum += pv;
+            }
+        sum = tmf::group_sum(sum);
+        const float inv = 1.0f / sum;
+        float dl = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[t][j] *= inv; dl += s[t][j] * dp[t][j]; }
+        dl = tmf::group_sum(dl);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[t][j] = s[t][j] * (dp[t][j] - dl) * scale;        // dS^T
+        if (g == 0) { st[0][q] = mx; st[1][q] = inv; st[2][q] = dl; }                       // rows q >= F: never used (p = 0 there)
+        const bf16x8 dsf = tmf::acc_frag(s[0], s[1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 dq = f32x4{0, 0, 0, 0};
+            tmf::mma(dq, frag_load_tr(Kimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), dsf);
+            if (q < F) {
+                float o[4] = {dq[0], dq[1], dq[2], dq[3]};
+                store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
+            }
+        }
+    }
+    tmf::wave_lds_fence();
+
+    // ---- part 2: per key tile kt -- S, dP (queries on rows, keys on lanes) -> dV, dK
+    // B operands of this orientation are the K / V rows of the tile: kf[kt], vf[kt] as loaded above
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        if (16 * kt >= F) break;
+        const int key = 16 * kt + r;
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            s[tt] = f32x4{0, 0, 0, 0}; dp[tt] = f32x4{0, 0, 0, 0};
+            const int qrow = 16 * tt + r;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qimg + qrow * LDI + 32 * ks + 8 * g);
+                const bf16x8 da = *reinterpret_cast<const bf16x8*>(Dimg + qrow * LDI + 32 * ks + 8 * g);
+                tmf::mma(s[tt], qa, kf[kt][ks]);
+                tmf::mma(dp[tt], da, vf[kt][ks]);
+            }
+            const int qb = 16 * tt + 4 * g;
+            const float4 m4 = *reinterpret_cast<const float4*>(&st[0][qb]);
+            const float4 i4 = *reinterpret_cast<const float4*>(&st[1][qb]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&st[2][qb]);
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (qb + j) < F && key < F;
+                const float pv = ok ? fast_exp2(s[tt][j] * c - mv[j]) * iv[j] : 0.f;
+                s[tt][j] = pv;                                            // P
+                dp[tt][j] = pv * (dp[tt][j] - dv4[j]) * scale;            // dS
+            }
+        }
+        const bf16x8 pf = tmf::acc_frag(s[0], s[1]);
+        const bf16x8 dsf = tmf::acc_frag(dp[0], dp[1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 dvv = f32x4{0, 0, 0, 0}, dkk = f32x4{0, 0, 0, 0};
+            tmf::mma(dvv, frag_load_tr(Dimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), pf);
+            tmf::mma(dkk, frag_load_tr(Qimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), dsf);
+            if (key < F) {
+                float a[4] = {dkk[0], dkk[1], dkk[2], dkk[3]}, bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
+                store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
+                store4(dvp + (long)key * sv + 16 * dt + 4 * g, bb);
+            }
+        }
+    }
+}
