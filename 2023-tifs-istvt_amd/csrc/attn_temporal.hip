@@ -437,8 +437,10 @@ extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out,
     if (use_mfma && dtype == DT_BF16 && F <= 32 && (dh == 64 || dh == 32)) {     // one wavefront per (b, p, h), MFMA tiles
         const long nprob = (long)B * P * heads;
         dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
-        if (dh == 64) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<64>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale);
-        else hipLaunchKernelGGL((tattn_mfma_fwd_kernel<32>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale);
+#define TATTN_F(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale)
+        if (dh == 64) { if (F <= 16) TATTN_F(64, 1); else TATTN_F(64, 2); }
+        else { if (F <= 16) TATTN_F(32, 1); else TATTN_F(32, 2); }
+#undef TATTN_F
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, tattn_fwd2_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P,
@@ -452,11 +454,14 @@ extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void
     static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
     // measured at C2 / C4 (tools/tattn_bench.py): F = 9 lane-cluster 170 us vs MFMA 203 us (its three 32-row LDS images
     // allow 8 wavefronts per CU); F = 17 850 us vs 336 us
-    if (use_mfma && dtype == DT_BF16 && F > 9 && F <= 32 && (dh == 64 || dh == 32)) {
+    static const int mfma_bwd_min = getenv("ISTVT_TATTN_MFMA_BWD_MINF") ? atoi(getenv("ISTVT_TATTN_MFMA_BWD_MINF")) : 1;
+    if (use_mfma && dtype == DT_BF16 && F >= mfma_bwd_min && F <= 32 && (dh == 64 || dh == 32)) {
         const long nprob = (long)B * P * heads;
         dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
-        if (dh == 64) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<64>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale);
-        else hipLaunchKernelGGL((tattn_mfma_bwd_kernel<32>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale);
+#define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale)
+        if (dh == 64) { if (F <= 16) TATTN_B(64, 1); else TATTN_B(64, 2); }
+        else { if (F <= 16) TATTN_B(32, 1); else TATTN_B(32, 2); }
+#undef TATTN_B
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, tattn_bwd2_kernel, (const T*)qk, (const T*)v, (const T*)dout,

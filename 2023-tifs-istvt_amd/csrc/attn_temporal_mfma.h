@@ -40,6 +40,33 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x4& lo, const f32x4& hi) {
 __device__ __forceinline__ void mma(f32x4& c, const bf16x8& a, const bf16x8& b) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// K = 16 step (F <= 16: the contraction over frames fits ONE 16-row tile): k-slot (g, i) <-> frame 4g + i, which is
+// exactly the accumulator row of the S tile -> the B operand is the accumulator converted to bf16, and the transposed
+// A operand is ONE ds_read_b64_tr_b16 (rows 4g .. 4g+3, lane r receives column col16 + r)
+typedef short short4k __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mma16(f32x4& c, const short4k& a, const short4k& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ short4k acc_frag4(const f32x4& v) {
+    bf16x4 f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (bf16_t)v[i];
+    return __builtin_bit_cast(short4k, f);
+}
+__device__ __forceinline__ short4k tr4(const bf16_t* img, int ld, int k0, int col16, int r) {
+    typedef short4v __attribute__((address_space(3))) * lds_ptr;
+    const int q = r >> 2, p = r & 3;
+    const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + (size_t)(k0 + q) * ld + col16 + 4 * p));
+    return __builtin_bit_cast(short4k, v);
+}
+// one product "acc += X^T(frames x 16 columns at col16)^T * Y" over the frames of NTL tiles: ya / yb are the
+// accumulator tiles whose rows are the frames (yb unused when NTL == 1)
+template <int NTL>
+__device__ __forceinline__ void mma_frames(f32x4& acc, const bf16_t* img, int ld, int col16, int g, int r, const f32x4& ya,
+                                           const f32x4& yb) {
+    if constexpr (NTL == 1) mma16(acc, tr4(img, ld, 4 * g, col16, r), acc_frag4(ya));
+    else mma(acc, frag_load_tr(img, ld, 4 * g, 16 + 4 * g, col16, r), acc_frag(ya, yb));
+}
 __device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same r)
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -53,24 +80,25 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
-// rows 0..31 x DH of a strided matrix -> wave-private LDS image [32][DH + IPAD]; rows >= nrows are zero-filled
-template <int DH>
+// rows 0 .. 16 NTL - 1 x DH of a strided matrix -> wave-private LDS image [16 NTL][DH + IPAD]; rows >= nrows are zero-filled
+template <int DH, int NTL>
 __device__ __forceinline__ void stage32(bf16_t* img, const bf16_t* __restrict__ src, long rstride, int nrows, int lane) {
     constexpr int LDI = DH + IPAD, VPR = DH / 8, RPI = 64 / VPR;      // rows per wave-instruction
 #pragma unroll
-    for (int it = 0; it < ROWS / RPI; ++it) {
+    for (int it = 0; it < 16 * NTL / RPI; ++it) {
         const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
         *reinterpret_cast<bf16x8*>(img + row * LDI + col) = row_frag(src, rstride, row, nrows, col);
     }
 }
 }  // namespace tmf
 
-template <int DH>
+// NTL = 16-row tiles that hold the F frames (1: F <= 16, 2: F <= 32)
+template <int DH, int NTL>
 __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              bf16_t* __restrict__ out, int B, int F, int P, int heads,
                                                              float scale) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4][tmf::ROWS * LDI];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4][16 * NTL * LDI];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
     const long prob = (long)blockIdx.x * 4 + wave;
     if (prob >= (long)B * P * heads) return;              // no workgroup-level synchronisation below
@@ -86,23 +114,24 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     bf16_t* Vimg = smem[wave];
     const float c = scale * TM_LOG2E;
 
-    tmf::stage32<DH>(Vimg, vp, sv, F, lane);
-    bf16x8 kf[2][KS];
+    tmf::stage32<DH, NTL>(Vimg, vp, sv, F, lane);
+    bf16x8 kf[NTL][KS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
     tmf::wave_lds_fence();
 
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NTL; ++u) {
         if (16 * u >= F) break;
         bf16x8 qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = tmf::row_frag(qp, sq, 16 * u + r, F, 32 * ks + 8 * g);
         f32x4 s[2];
+        s[1] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTL; ++t) {
             s[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) tmf::mma(s[t], kf[t][ks], qf[ks]);
@@ -110,7 +139,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
         // softmax over keys: lane owns query r, keys 16t + 4g + j
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float z = (16 * t + 4 * g + j) < F ? s[t][j] * c : -INFINITY;
@@ -120,7 +149,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
         mx = tmf::group_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float pv = fast_exp2(s[t][j] - mx);
@@ -129,12 +158,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
             }
         sum = tmf::group_sum(sum);
         const float inv = 1.0f / sum;
-        const bf16x8 pf = tmf::acc_frag(s[0], s[1]);
         const int q = 16 * u + r;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             f32x4 o = f32x4{0, 0, 0, 0};
-            tmf::mma(o, frag_load_tr(Vimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), pf);
+            tmf::mma_frames<NTL>(o, Vimg, LDI, 16 * dt, g, r, s[0], s[1]);
             if (q < F) {
                 float ov[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
                 store4(op + (long)q * sv + 16 * dt + 4 * g, ov);
@@ -143,14 +171,15 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     }
 }
 
-template <int DH>
+template <int DH, int NTL>
 __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqk,
                                                              bf16_t* __restrict__ dv, int B, int F, int P, int heads,
                                                              float scale) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * tmf::ROWS * LDI];
-    __shared__ __attribute__((aligned(16))) float stat[4][3][tmf::ROWS];
+    constexpr int IMG = 16 * NTL * LDI;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * IMG];
+    __shared__ __attribute__((aligned(16))) float stat[4][3][16 * NTL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
     const long prob = (long)blockIdx.x * 4 + wave;
     if (prob >= (long)B * P * heads) return;
@@ -167,18 +196,18 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     bf16_t* dkp = dqp + inner;
     bf16_t* dvp = dv + row0 * inner + h * DH;
     bf16_t* Qimg = smem[wave];
-    bf16_t* Kimg = Qimg + tmf::ROWS * LDI;
-    bf16_t* Dimg = Kimg + tmf::ROWS * LDI;
-    float (*st)[tmf::ROWS] = stat[wave];
+    bf16_t* Kimg = Qimg + IMG;
+    bf16_t* Dimg = Kimg + IMG;
+    float (*st)[16 * NTL] = stat[wave];
     const float c = scale * TM_LOG2E;
 
-    tmf::stage32<DH>(Qimg, qp, sq, F, lane);
-    tmf::stage32<DH>(Kimg, kp, sq, F, lane);
-    tmf::stage32<DH>(Dimg, dop, sv, F, lane);
+    tmf::stage32<DH, NTL>(Qimg, qp, sq, F, lane);
+    tmf::stage32<DH, NTL>(Kimg, kp, sq, F, lane);
+    tmf::stage32<DH, NTL>(Dimg, dop, sv, F, lane);
     // operands used un-transposed, straight from global memory in fragment layout (row 16t + r, columns 32ks + 8g)
-    bf16x8 kf[2][KS], vf[2][KS];
+    bf16x8 kf[NTL][KS], vf[NTL][KS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
@@ -188,7 +217,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
 
     // ---- part 1: per query tile u -- S^T, dP^T (keys on rows, queries on lanes), statistics, dQ
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NTL; ++u) {
         if (16 * u >= F) break;
         const int q = 16 * u + r;
         bf16x8 qf[KS], dof[KS];
@@ -198,8 +227,9 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
             dof[ks] = tmf::row_frag(dop, sv, q, F, 32 * ks + 8 * g);
         }
         f32x4 s[2], dp[2];
+        s[1] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTL; ++t) {
             s[t] = f32x4{0, 0, 0, 0}; dp[t] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -209,7 +239,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float z = (16 * t + 4 * g + j) < F ? s[t][j] * c : -INFINITY;
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         mx = tmf::group_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float pv = fast_exp2(s[t][j] - mx);
@@ -230,20 +260,19 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         const float inv = 1.0f / sum;
         float dl = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[t][j] *= inv; dl += s[t][j] * dp[t][j]; }
         dl = tmf::group_sum(dl);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) s[t][j] = s[t][j] * (dp[t][j] - dl) * scale;        // dS^T
         if (g == 0) { st[0][q] = mx; st[1][q] = inv; st[2][q] = dl; }                       // rows q >= F: never used (p = 0 there)
-        const bf16x8 dsf = tmf::acc_frag(s[0], s[1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             f32x4 dq = f32x4{0, 0, 0, 0};
-            tmf::mma(dq, frag_load_tr(Kimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), dsf);
+            tmf::mma_frames<NTL>(dq, Kimg, LDI, 16 * dt, g, r, s[0], s[1]);
             if (q < F) {
                 float o[4] = {dq[0], dq[1], dq[2], dq[3]};
                 store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
@@ -255,12 +284,13 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     // ---- part 2: per key tile kt -- S, dP (queries on rows, keys on lanes) -> dV, dK
     // B operands of this orientation are the K / V rows of the tile: kf[kt], vf[kt] as loaded above
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < NTL; ++kt) {
         if (16 * kt >= F) break;
         const int key = 16 * kt + r;
         f32x4 s[2], dp[2];
+        s[1] = f32x4{0, 0, 0, 0}; dp[1] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < NTL; ++tt) {
             s[tt] = f32x4{0, 0, 0, 0}; dp[tt] = f32x4{0, 0, 0, 0};
             const int qrow = 16 * tt + r;
 #pragma unroll
@@ -283,13 +313,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
                 dp[tt][j] = pv * (dp[tt][j] - dv4[j]) * scale;            // dS
             }
         }
-        const bf16x8 pf = tmf::acc_frag(s[0], s[1]);
-        const bf16x8 dsf = tmf::acc_frag(dp[0], dp[1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             f32x4 dvv = f32x4{0, 0, 0, 0}, dkk = f32x4{0, 0, 0, 0};
-            tmf::mma(dvv, frag_load_tr(Dimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), pf);
-            tmf::mma(dkk, frag_load_tr(Qimg, LDI, 4 * g, 16 + 4 * g, 16 * dt, r), dsf);
+            tmf::mma_frames<NTL>(dvv, Dimg, LDI, 16 * dt, g, r, s[0], s[1]);
+            tmf::mma_frames<NTL>(dkk, Qimg, LDI, 16 * dt, g, r, dp[0], dp[1]);
             if (key < F) {
                 float a[4] = {dkk[0], dkk[1], dkk[2], dkk[3]}, bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
                 store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
