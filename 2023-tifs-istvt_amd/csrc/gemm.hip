@@ -69,6 +69,37 @@ __device__ __forceinline__ float gelu_grad_fast(float u) {
     return fmaf(u * 0.39894228040143267794f, e, 0.5f * (1.0f + copysignf(erf_abs, x)));
 }
 
+// Two elements at a time: the multiplies / FMAs become v_pk_mul_f32 / v_pk_fma_f32 (two lanes-worth per issue), only
+// the two transcendentals and the sign transfer stay scalar.  The GELU epilogues are pure VALU time with the MFMA
+// pipe idle (~15 k cycles per 256x256 tile against 32 k for its K loop), so instruction count is what they cost.
+typedef float gf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gf2 erf_abs2(gf2 ax, gf2& e) {
+    const gf2 arg = ax * ax * gf2{-1.4426950408889634f, -1.4426950408889634f};
+    e = gf2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};                  // exp(-ax^2)
+    const gf2 d = ax * gf2{0.3275911f, 0.3275911f} + gf2{1.0f, 1.0f};
+    const gf2 t = gf2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    gf2 p = t * gf2{1.061405429f, 1.061405429f} + gf2{-1.453152027f, -1.453152027f};
+    p = p * t + gf2{1.421413741f, 1.421413741f};
+    p = p * t + gf2{-0.284496736f, -0.284496736f};
+    p = p * t + gf2{0.254829592f, 0.254829592f};
+    return gf2{1.0f, 1.0f} - p * t * e;                                                      // erf(ax), ax >= 0
+}
+__device__ __forceinline__ gf2 gelu_fast2(gf2 u) {
+    const gf2 x = u * gf2{0.70710678118654752440f, 0.70710678118654752440f};
+    gf2 e;
+    const gf2 ea = erf_abs2(gf2{fabsf(x.x), fabsf(x.y)}, e);
+    const gf2 er = gf2{copysignf(ea.x, x.x), copysignf(ea.y, x.y)};
+    const gf2 hu = u * gf2{0.5f, 0.5f};
+    return hu * er + hu;
+}
+__device__ __forceinline__ gf2 gelu_grad_fast2(gf2 u) {
+    const gf2 x = u * gf2{0.70710678118654752440f, 0.70710678118654752440f};
+    gf2 e;                                                                                   // exp(-u*u/2)
+    const gf2 ea = erf_abs2(gf2{fabsf(x.x), fabsf(x.y)}, e);
+    const gf2 er = gf2{copysignf(ea.x, x.x), copysignf(ea.y, x.y)};
+    return (u * gf2{0.39894228040143267794f, 0.39894228040143267794f}) * e + (er * gf2{0.5f, 0.5f} + gf2{0.5f, 0.5f});
+}
+
 #include "gemm256.h"
 #include "gemm256r.h"
 #include "gemm256p.h"

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
                 if (EPI == EPI_GELU_BWD) {
                     const bf16x8 u = __builtin_bit_cast(bf16x8, sv[pass * 2 + it]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_fast((float)u[j]);
+                    for (int j = 0; j < 8; j += 2) {
+                        const gf2 gg = gelu_grad_fast2(gf2{(float)u[j], (float)u[j + 1]});
+                        v[j] *= gg.x; v[j + 1] *= gg.y;
+                    }
                 } else if (SIDE) {
                     const bf16x8 u = __builtin_bit_cast(bf16x8, sv[pass * 2 + it]);
 #pragma unroll
@@ -265,7 +268,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
                 if (EPI == EPI_GELU_FWD) {
                     bf16x8 o2;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o2[j] = (bf16_t)gelu_fast(v[j]);
+                    for (int j = 0; j < 8; j += 2) {
+                        const gf2 gv = gelu_fast2(gf2{v[j], v[j + 1]});
+                        o2[j] = (bf16_t)gv.x; o2[j + 1] = (bf16_t)gv.y;
+                    }
                     held2[it] = __builtin_bit_cast(u32x4, o2);
                     __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, 0);
                 }
