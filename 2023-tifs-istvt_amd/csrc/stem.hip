@@ -14,6 +14,7 @@
 //
 // All of these are HBM-bound (AI <= 4.5 flop/B): coalesced 16-byte accesses along C.
 #include "common.h"
+#include <cstdlib>
 
 // A finalized BatchNorm is passed around as ONE pointer `bnp` to a float [4][C] pack:
 //   row 0 mean, row 1 rstd, row 2 scale = gamma * rstd, row 3 beta.
@@ -447,6 +448,7 @@ struct DwArgs {
     int mask_pre, mask_post;
     const void* addsrc; int Ha, Wa;                                  // += addsrc[f][y/2][x/2] at even (y,x)
     double* st_s1; double* st_s2;                                    // fused BN-backward statistics (of m_bn)
+    unsigned long long* dbg;                                         // diagnostic builds only (-DISTVT_DW_DIAG)
 };
 
 // load the (TH+2)x(TW+2)xCC input tile (zero outside the image; the on-load transform only
@@ -513,7 +515,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
     const long f = t / (tiles_x * tiles_y);
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+#ifdef ISTVT_DW_DIAG
+    unsigned long long tstamp[5];
+    tstamp[0] = __builtin_amdgcn_s_memtime();
+#endif
     dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
+#ifdef ISTVT_DW_DIAG
+    tstamp[1] = __builtin_amdgcn_s_memtime();
+#endif
 
     const int ch = tid % DW_NCH;                  // 8-channel chunk of this thread (same for all its items)
     const int c = c0 + ch * 8;
@@ -530,6 +539,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         }
     }
     __syncthreads();
+#ifdef ISTVT_DW_DIAG
+    tstamp[2] = __builtin_amdgcn_s_memtime();
+#endif
 
     float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -587,6 +599,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         }
         store8((T*)p.out + off, acc);
     }
+#ifdef ISTVT_DW_DIAG
+    tstamp[3] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tstamp[4] = __builtin_amdgcn_s_memtime();
+    if (p.dbg && (blockIdx.x % 997) == 0 && blockIdx.x / 997 < 32 && (tid & 63) == 0) {
+        unsigned long long* d = p.dbg + ((blockIdx.x / 997) * 4 + (tid >> 6)) * 5;
+        for (int i = 0; i < 5; ++i) d[i] = tstamp[i];
+    }
+#endif
     if (p.st_s1) {
         // reduce over the pixels of a wave that share this channel chunk (lanes with equal tid % DW_NCH)
 #pragma unroll
@@ -692,6 +713,10 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
     a.in_bn = in_bn; a.in_relu = in_relu; a.flip = flip;
     a.msrc = msrc; a.m_bn = m_bn; a.mask_pre = mask_pre; a.mask_post = mask_post;
     a.addsrc = addsrc; a.Ha = Ha; a.Wa = Wa; a.st_s1 = st_s1; a.st_s2 = st_s2;
+    a.dbg = nullptr;
+#ifdef ISTVT_DW_DIAG
+    if (getenv("ISTVT_DW_DBGPTR")) a.dbg = (unsigned long long*)strtoull(getenv("ISTVT_DW_DBGPTR"), nullptr, 0);
+#endif
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
     const long nblk = tiles * ((C + DW_CC - 1) / DW_CC);
     if (nblk > 0x7fffffffL) return ISTVT_ERR_SHAPE;
