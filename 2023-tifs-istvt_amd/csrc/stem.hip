@@ -501,10 +501,13 @@ __device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, 
     }
 }
 
-template <typename T>
+// EPI = false: plain convolution (the forward launches).  The mask / skip-add / statistics epilogue of the input-
+// gradient launches costs ~90 registers; compiled into one kernel it left the forward at two workgroups per CU too.
+template <typename T, bool EPI>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
     __shared__ float sred[2][4][DW_CC];   // [s1|s2][wave][channel]
+    __shared__ __attribute__((aligned(16))) float wsm[9][DW_CC];
     const int tid = threadIdx.x;
     const int tiles_x = (p.W + DW_TW - 1) / DW_TW, tiles_y = (p.H + DW_TH - 1) / DW_TH;
     // 1-D grid, channel chunk fastest: the workgroups that share a pixel's 128-byte lines (its other
@@ -526,17 +529,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 
     const int ch = tid % DW_NCH;                  // 8-channel chunk of this thread (same for all its items)
     const int c = c0 + ch * 8;
-    // weights are passed tap-major ([9][C]): a thread's 8 channels of one tap are one 32-byte load
-    // (the PyTorch [C][9] order costs 72 scalar loads per thread and dominated the kernel)
-    float wv[9][8];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    // weights are passed tap-major ([9][C]).  They live in LDS, not in registers: 72 weight registers kept the kernel at
+    // 186 VGPRs = two workgroups per CU, and its phases (tile fetch 5.6 k cycles, convolution 5.3 k) only overlap
+    // ACROSS workgroups (tools/dw_diag.py); the two extra LDS reads per tap are cheaper than that.
+    if (tid < 9 * DW_NCH) {
+        const int tap = tid / DW_NCH, wc = (tid % DW_NCH) * 8;
         const int src_tap = p.flip ? 8 - tap : tap;
-        if (c < p.C) load8(p.w + (long)src_tap * p.C + c, wv[tap]);
-        else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wv[tap][j] = 0.f;
-        }
+        float w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c0 + wc < p.C) load8(p.w + (long)src_tap * p.C + c0 + wc, w8);
+        store8(&wsm[tap][wc], w8);
     }
     __syncthreads();
 #ifdef ISTVT_DW_DIAG
@@ -544,23 +545,27 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 #endif
 
     float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < DW_ITEMS; ++k) {
         const int pix = tid / DW_NCH + DW_PIXSTEP * k;
         const int py = pix / DW_TW, px = pix % DW_TW;
         const int y = y0 + py, x = x0 + px;
         if (y >= p.H || x >= p.W || c >= p.C) continue;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int wo = ch * 8;
+        asm volatile("" : "+v"(wo));              // opaque per item: the weight reads must not be hoisted into 72 registers
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                float v[8];
+                float v[8], w8[8];
                 load8(tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8, v);
+                load8(&wsm[dy * 3 + dx][wo], w8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v[j] * wv[dy * 3 + dx][j];
+                for (int j = 0; j < 8; ++j) acc[j] += v[j] * w8[j];
             }
         const long off = ((f * p.H + y) * p.W + x) * p.C + c;
+        if constexpr (EPI) {
         // epilogue order: ReLU mask of the rep path (pre) -> add the skip-path gradient at the
         // stride-2 positions -> ReLU mask that covers both paths (post)
         float mv[8], z[8];
@@ -597,6 +602,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
                 st2[j] += d * (mv[j] - mu[j]) * rs[j];
             }
         }
+        }
         store8((T*)p.out + off, acc);
     }
 #ifdef ISTVT_DW_DIAG
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         for (int i = 0; i < 5; ++i) d[i] = tstamp[i];
     }
 #endif
-    if (p.st_s1) {
+    if (EPI && p.st_s1) {
         // reduce over the pixels of a wave that share this channel chunk (lanes with equal tid % DW_NCH)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -721,7 +727,8 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
     const long nblk = tiles * ((C + DW_CC - 1) / DW_CC);
     if (nblk > 0x7fffffffL) return ISTVT_ERR_SHAPE;
     dim3 grid((unsigned)nblk);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T>), grid, dim3(256), 0, stream, a));
+    if (msrc || addsrc || st_s1) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), grid, dim3(256), 0, stream, a));
+    else DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), grid, dim3(256), 0, stream, a));
     return istvt_check_launch();
 }
 
