@@ -325,7 +325,8 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         // measured at the model's shapes (same device, interleaved): the 4-slot ring is ~5 % faster for
         // the k-contiguous case, the 2-stage kernel ~8 % faster for the transposed-operand case
         static const int persist = getenv("ISTVT_GEMM_PERSIST") ? atoi(getenv("ISTVT_GEMM_PERSIST")) : 1;
-        const bool p_ok = out_mode == 0 && splitk == 1 && K > 96 && (!bias || alpha == 1.0f) &&!(epi == EPI_GELU_BWD && residual) && !(epi == EPI_GELU_FWD && residual);
+        const bool q_ok = (long)M * lda * 2 < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K >= 32;
+        const bool p_ok = out_mode == 0 && splitk == 1 && (K > 96 || q_ok) && (!bias || alpha == 1.0f) &&!(epi == EPI_GELU_BWD && residual) && !(epi == EPI_GELU_FWD && residual);
         if (dbg == 0 && persist && a_kc && p_ok) {
             // persistent NT kernel: one workgroup per CU walks its tiles with the LDS ring kept full across tiles
             static int cus = 0;
@@ -357,12 +358,13 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 return istvt_check_launch();
             }
 #endif
-            const bool q_ok = (long)M * lda * 2 < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K > 64;
             if (qk && q_ok) {       // 64-deep K tiles in 128-byte-row units, two wave groups in ping-pong (gemm256q.h)
                 if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
                 else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
                 else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), dim3(G), block, 0, stream, a);
                 else hipLaunchKernelGGL((gemm256q_kernel<0, false>), dim3(G), block, 0, stream, a);
+            } else if (K <= 96) {
+                hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
             } else if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
             else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
             else if (residual) hipLaunchKernelGGL((gemm256p_kernel<0, true>), dim3(G), block, 0, stream, a);

@@ -63,7 +63,7 @@ __device__ __forceinline__ void slot_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// EPI / SIDE as in gemm256p_kernel.  Requires K > 64 (two or more K tiles), 16-byte aligned rows, and operands
+// EPI / SIDE as in gemm256p_kernel.  Requires 16-byte aligned rows and operands
 // smaller than 2 GiB (32-bit buffer offsets).
 // DBG (diagnostic builds only, -DISTVT_GEMM_DIAG + ISTVT_GEMM_QDBG=n): 1 = no DMA inside the K loop, 2 = no MFMA,
 // 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2.
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             ++KT;
             U0 += 4;
         };
-        ktile(true, false);
+        ktile(true, nkt == 1);
         if (p.bias) {
             // the bias DMA was issued in phase A of the first K tile, before units U0-4+6..9: phase B's wait covered it
 #pragma unroll
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             }
         }
         for (int s = 1; s < nkt - 1; ++s) ktile(false, false);
-        ktile(false, true);
+        if (nkt > 1) ktile(false, true);
 
         if (wm == 0) slot_barrier();           // re-align the two groups: both run the epilogue together
         if (DBG & 8) t_stamp[1] = __builtin_amdgcn_s_memtime();

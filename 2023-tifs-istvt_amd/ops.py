@@ -168,13 +168,15 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
     big = (A.dtype == torch.bfloat16 and bool(a_kc) == bool(b_kc) and M >= G256_MIN and N >= G256_MIN and N % 8 == 0
            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and (K % 8 == 0 if a_kc else M % 8 == 0))
     if big:
-        persistent = (a_kc and out_mode == 0 and splitk == 1 and K > 96 and (bias is None or alpha == 1.0)
+        q_ok = M * lda * 2 < 0x7fffffff and N * ldb * 2 < 0x7fffffff and K >= 32
+        persistent = (a_kc and out_mode == 0 and splitk == 1 and (K > 96 or q_ok) and (bias is None or alpha == 1.0)
                       and not (epi != 0 and residual is not None) and os.environ.get('ISTVT_GEMM_PERSIST', '1') != '0')
         if persistent:
             side = 'true' if (epi == 0 and residual is not None) else 'false'
-            q_ok = M * lda * 2 < 0x7fffffff and N * ldb * 2 < 0x7fffffff and K > 64
             if q_ok and os.environ.get('ISTVT_GEMM_Q', '1') != '0':
                 return 'gemm256q_kernel<%d, %s, 0>' % (epi, side)
+            if K <= 96:
+                return 'gemm256r_kernel<false, 0>'
             return 'gemm256p_kernel<%d, %s>' % (epi, side)
         if a_kc:
             return 'gemm256r_kernel<false, 0>'

@@ -284,6 +284,8 @@ def all_checks():
         for mode in ('fwd', 'dgrad', 'wgrad'):
             out.append(('gemm_exact_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode)))
             out.append(('gemm_exact_big_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 515, 728, 1544)))
+            out.append(('gemm_exact_k64_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 1030, 128, 64)))
+            out.append(('gemm_exact_k40_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 700, 72, 40)))
         for mode in ('fwd_bias_res', 'fwd_gelu', 'dgrad_gelu', 'wgrad', 'head'):
             out.append(('gemm_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_real(dt, mode)))
         out.append(('gemm_padded_rows_%s' % tag, lambda dt=dt: gemm_padded(dt)))
