@@ -522,6 +522,23 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     unsigned long long tstamp[5];
     tstamp[0] = __builtin_amdgcn_s_memtime();
 #endif
+    // epilogue operands (ReLU-mask source, stride-2 skip gradient) of this thread's four outputs: requested BEFORE the
+    // tile is staged -- loaded per item after the barrier they were dependent HBM latencies inside the convolution
+    typename Mma<T>::frag mraw[DW_ITEMS], araw[DW_ITEMS];
+    if constexpr (EPI) {
+        const int cq = c0 + (tid % DW_NCH) * 8;
+#pragma unroll
+        for (int k = 0; k < DW_ITEMS; ++k) {
+            const int pix = tid / DW_NCH + DW_PIXSTEP * k;
+            const int y = y0 + pix / DW_TW, x = x0 + pix % DW_TW;
+            mraw[k] = Mma<T>::zero(); araw[k] = Mma<T>::zero();
+            if (y < p.H && x < p.W && cq < p.C) {
+                if (p.msrc) mraw[k] = frag_load((const T*)p.msrc + ((f * p.H + y) * p.W + x) * p.C + cq);
+                if (p.addsrc && !(y & 1) && !(x & 1))
+                    araw[k] = frag_load((const T*)p.addsrc + ((f * p.Ha + (y >> 1)) * p.Wa + (x >> 1)) * p.C + cq);
+            }
+        }
+    }
     dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
 #ifdef ISTVT_DW_DIAG
     tstamp[1] = __builtin_amdgcn_s_memtime();
@@ -545,12 +562,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 #endif
 
     float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int k = 0; k < DW_ITEMS; ++k) {
+    auto item = [&](const int k) {
         const int pix = tid / DW_NCH + DW_PIXSTEP * k;
         const int py = pix / DW_TW, px = pix % DW_TW;
         const int y = y0 + py, x = x0 + px;
-        if (y >= p.H || x >= p.W || c >= p.C) continue;
+        if (y >= p.H || x >= p.W || c >= p.C) return;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int wo = ch * 8;
         asm volatile("" : "+v"(wo));              // opaque per item: the weight reads must not be hoisted into 72 registers
@@ -571,7 +587,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         float mv[8], z[8];
         const bool have_m = p.msrc != nullptr;
         if (have_m) {
-            load8((const T*)p.msrc + off, mv);
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mv[j] = (float)mraw[k][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mv[j] = mraw[k].v[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = mv[j];
             if (p.m_bn) bn_affine8(z, p.m_bn, p.C, c);
@@ -582,7 +604,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         }
         if (p.addsrc && !(y & 1) && !(x & 1)) {
             float a[8];
-            load8((const T*)p.addsrc + ((f * p.Ha + (y >> 1)) * p.Wa + (x >> 1)) * p.C + c, a);
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (float)araw[k][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = araw[k].v[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += a[j];
         }
@@ -604,6 +632,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         }
         }
         store8((T*)p.out + off, acc);
+    };
+    if constexpr (EPI) {        // unrolled by hand: the prefetched fragments are indexed by k
+        static_assert(DW_ITEMS == 4, "item(0..3)");
+        item(0); item(1); item(2); item(3);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < DW_ITEMS; ++k) item(k);
     }
 #ifdef ISTVT_DW_DIAG
     tstamp[3] = __builtin_amdgcn_s_memtime();
@@ -662,6 +697,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
         const long f = t / (tiles_x * tiles_y);
         const int y0 = ty * DW_TH, x0 = tx * DW_TW;
         __syncthreads();
+        // the output-gradient rows of this thread's items are requested BEFORE the tile is staged: issued after the
+        // barrier they were a second exposed HBM latency per tile
+        typename Mma<T>::frag draw[DW_ITEMS];
+#pragma unroll
+        for (int k = 0; k < DW_ITEMS; ++k) {
+            const int pix = tid / DW_NCH + DW_PIXSTEP * k;
+            const int y = y0 + pix / DW_TW, x = x0 + pix % DW_TW;
+            if (y < H && x < W && c < C) draw[k] = frag_load(dout + ((f * H + y) * W + x) * C + c);
+        }
         dw_load_tile<T>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
         __syncthreads();
 #pragma unroll
@@ -671,7 +715,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
             const int y = y0 + py, x = x0 + px;
             if (y >= H || x >= W || c >= C) continue;
             float d[8];
-            load8(dout + ((f * H + y) * W + x) * C + c, d);
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = (float)draw[k][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = draw[k].v[j];
+            }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
