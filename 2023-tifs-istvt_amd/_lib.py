@@ -35,6 +35,11 @@ SIGNATURES = {
     'istvt_bn_bwd_stats': [P, P, P, P, P, L, I, I, P],
     'istvt_bn_bwd_apply': [P, P, P, P, P, P, P, P, P, L, I, I, P],
     'istvt_im2col_conv1': [P, P, I, I, I, P],
+    'istvt_conv1_fwd': [P, P, P, I, I, I, P],
+    'istvt_conv2_fwd': [P, P, P, P, I, I, I, P],
+    'istvt_conv2_dgrad': [P, P, P, P, P, I, I, I, P],
+    'istvt_conv2_wgrad': [P, P, P, P, P, I, I, I, P],
+    'istvt_conv2_wgrad_slabs': [],
     'istvt_col2im_conv1': [P, P, I, I, I, P],
     'istvt_im2col3x3': [P, P, I, P, I, I, I, I, I, P],
     'istvt_col2im3x3': [P, P, P, P, I, I, I, I, I, P],

@@ -9,6 +9,8 @@ returns ``None`` for it, which removes one zero-fill and one add pass per parame
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -90,16 +92,60 @@ class FrameDiffFn(Function):
         return ops.frame_diff(g, *ctx.geom, adjoint=True), None, None, None
 
 
+# Weight gradients on a second HIP stream.  Nothing downstream in the backward pass reads a weight gradient, so the
+# TN GEMM + split-K reduce of a Linear are enqueued on a side stream that waits for the main stream at the point of
+# the call (dy and x are complete there) and is joined back into the main stream by an end-of-backward callback.
+# The hardware then fills the partial last round of the persistent input-gradient GEMMs, and the CUs the
+# bandwidth-bound kernels leave idle, with weight-gradient workgroups.  Only used when the gradient lands directly
+# in the parameter's .grad (GradBucket(fuse_accumulate=True)): a returned tensor would be consumed by autograd on
+# the main stream.  ISTVT_WGRAD_STREAM=0 (or set_wgrad_overlap(False)) serialises everything on one stream.
+_overlap = {'on': os.environ.get('ISTVT_WGRAD_STREAM', '1') != '0', 'streams': {}, 'pending': {}}
+
+
+def set_wgrad_overlap(on: bool):
+    _overlap['on'] = bool(on)
+
+
+def _join_side(dev):
+    main = _overlap['pending'].pop(dev, None)
+    if main is not None:
+        main.wait_stream(_overlap['streams'][dev])
+
+
 def _wgrad(dy, x, weight):
     buf, ret = _target(weight)
-    ops.linear_wgrad(dy, x, out=buf.view(weight.shape[0], -1))
-    return ret
+    out = buf.view(weight.shape[0], -1)
+    if not (_overlap['on'] and ret is None and dy.is_cuda):
+        ops.linear_wgrad(dy, x, out=out)
+        return ret
+    dev = dy.device.index
+    side = _overlap['streams'].get(dev)
+    if side is None:
+        side = _overlap['streams'][dev] = torch.cuda.Stream(device=dy.device, priority=int(os.environ.get('ISTVT_WGRAD_PRIO', '0')))
+    main = torch.cuda.current_stream(dy.device)
+    if dev not in _overlap['pending']:
+        _overlap['pending'][dev] = main
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        ops.linear_wgrad(dy, x, out=out)
+    dy.record_stream(side)      # the caching allocator must not hand these blocks out again before the side
+    x.record_stream(side)       # stream has read them
+    return None
 
 
 def _bgrad(dy, bias):
     if bias is None:
         return None
     buf, ret = _target(bias)
+    side = _overlap['streams'].get(dy.device.index) if dy.is_cuda else None
+    if os.environ.get('ISTVT_BGRAD_SIDE', '0') == '1' and _overlap['on'] and ret is None and side is not None \
+            and dy.device.index in _overlap['pending']:
+        side.wait_stream(torch.cuda.current_stream(dy.device))
+        with torch.cuda.stream(side):
+            ops.colsum(dy, out=buf)
+        dy.record_stream(side)
+        return None
     ops.colsum(dy, out=buf)
     return ret
 

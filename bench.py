@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--attn-fp8', action='store_true', help='fp8 (e4m3) operands in the spatial-attention MFMAs (configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--no-wgrad-overlap', action='store_true',
+                    help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
     return ap.parse_args()
 
 
@@ -93,6 +95,7 @@ def main():
     import istvt_pkg
     istvt_pkg.load()
     from istvt_amd import ops, parallel
+    from istvt_amd import functional as Fn
     from istvt_amd import stem as stem_mod
     from istvt_amd.network.vivit.vivit import XceptionVidTr
 
@@ -111,12 +114,16 @@ def main():
     x = torch.randn((a.batch, a.frames, 3, a.size, a.size), generator=g).to(dev)
     labels = (torch.rand((a.batch,), generator=g) > 0.5).float().to(dev)
 
-    def step():
+    if a.no_wgrad_overlap:
+        Fn.set_wgrad_overlap(False)
+
+    def step(reduce=True):
         bucket.zero()
         logits = model(x)
         loss = crit(logits.view(-1), labels)
         loss.backward()
-        bucket.all_reduce()
+        if reduce:
+            bucket.all_reduce()
         opt.step()
         return loss
 
@@ -145,7 +152,8 @@ def main():
     if rank == 0 and not a.no_kernel_profile:
         ops.gemm_profile = []
         ops.kernel_profile = []
-        step()
+        Fn.set_wgrad_overlap(False)         # one stream: a kernel's duration is then its own, not its neighbour's
+        step(reduce=False)                  # rank 0 alone: no collective in this extra step
         torch.cuda.synchronize(dev)
         recs, ops.gemm_profile = ops.gemm_profile, None
         krecs, ops.kernel_profile = ops.kernel_profile, None
@@ -167,6 +175,17 @@ def main():
             d[0] += flops
             d[1] += ev0.elapsed_time(ev1) * 1e-3
             d[2] += 1
+        if os.environ.get('ISTVT_BENCH_SHAPES'):   # per (kernel, M, N, K) table for tuning, written beside the logs
+            sh = {}
+            for ev0, ev1, flops, variant, shape, kname in recs:
+                d = sh.setdefault((kname, shape), [0.0, 0.0, 0])
+                d[0] += flops
+                d[1] += ev0.elapsed_time(ev1) * 1e-3
+                d[2] += 1
+            with open(os.environ['ISTVT_BENCH_SHAPES'], 'w') as fh:
+                for (kname, shape), d in sorted(sh.items(), key=lambda kv: -kv[1][1]):
+                    fh.write('%-44s M=%-8d N=%-5d K=%-8d x%-3d %8.3f ms  %7.1f TF/s\n'
+                             % (kname, shape[0], shape[1], shape[2], d[2], d[1] * 1e3, d[0] / d[1] / 1e12))
         tot_f = sum(d[0] for d in by.values())
         tot_t = sum(d[1] for d in by.values())
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS

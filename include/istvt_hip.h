@@ -140,6 +140,21 @@ int istvt_im2col3x3(const void* src, const float* bnp, int relu, void* col, int 
 int istvt_col2im3x3(const void* dcol, const void* u, const float* bnp, void* dz, int frames, int H, int W, int C,
                     int dtype, istvt_stream_t stream);
 
+/* The same two convolutions computed directly (no im2col matrix in HBM); xception.py:118-123,193-199.
+ * conv1_fwd: x float [frames][3][S][S], w float [32][3][3][3] (conv1.weight as stored) -> u1 [frames*Ho*Wo][32] (dtype).
+ * conv2_* are bf16 only: u1 = raw conv1 output [frames][H][W][32], bnp = bn1's finalized pack (ReLU implied),
+ * w = bf16 [64][(dy,dx,ci)].  fwd -> u2 [frames][H-2][W-2][64]; dgrad: du2 -> dz1 [frames][H][W][32] masked by
+ * relu'(bn1(u1)); wgrad: dw float [64][(dy,dx,ci)] += sum over pixels, slabs = caller-owned float workspace of
+ * istvt_conv2_wgrad_slabs() * 64 * 288 elements. */
+int istvt_conv1_fwd(const float* x, const float* w, void* u1, int frames, int S, int dtype, istvt_stream_t stream);
+int istvt_conv2_fwd(const void* u1, const float* bnp, const void* w, void* u2, int frames, int H, int W,
+                    istvt_stream_t stream);
+int istvt_conv2_dgrad(const void* du2, const void* w, const void* u1, const float* bnp, void* dz1, int frames, int H,
+                      int W, istvt_stream_t stream);
+int istvt_conv2_wgrad(const void* du2, const void* u1, const float* bnp, float* slabs, float* dw, int frames, int H,
+                      int W, istvt_stream_t stream);
+int istvt_conv2_wgrad_slabs(void);
+
 /* depthwise 3x3 s1 p1 (SeparableConv2d.conv1, xception.py:43), LDS-tiled.  w: float[9][C] (tap-major);
  * the weight gradient dw is float[C][9] (PyTorch order).
  * forward: in_bn (+in_relu) = the preceding BatchNorm+ReLU applied on load (xception.py:67,73).

@@ -557,6 +557,52 @@ def im2col_check(dtype, Fr=2, S_=33):
     return e, TOL[dtype]
 
 
+def conv_dense_check(dtype, Fr=2, S_=33):
+    """conv1 forward (both dtypes) and conv2 forward / input gradient / weight gradient (bf16) computed directly
+    from the activations vs F.conv2d in float64 on the same (storage-rounded) operands."""
+    from istvt_amd import _lib, stem as S
+    L = _lib.lib()
+    x = rnd((Fr, 3, S_, S_), torch.float32, 11)
+    w1 = rnd((32, 3, 3, 3), torch.float32, 12, 0.2)
+    H1 = (S_ - 3) // 2 + 1
+    u1 = torch.empty((Fr * H1 * H1, 32), dtype=dtype, device=DEV)
+    _lib.check(L.istvt_conv1_fwd(x.data_ptr(), w1.data_ptr(), u1.data_ptr(), Fr, S_, ops._DT[dtype], ops._stream()), 'conv1')
+    r1 = torch.nn.functional.conv2d(x.double(), w1.double(), None, 2, 0)
+    e = relerr(u1, _nhwc(r1))
+    if dtype != torch.bfloat16:
+        return e, TOL[dtype]
+    C = 32
+    u = rnd((Fr, C, H1, H1), dtype, 14)
+    bn = S.BNState(C, DEV)
+    bn.scale.copy_(rnd((C,), torch.float32, 15, 0.5)); bn.beta.copy_(rnd((C,), torch.float32, 16, 0.3))
+    bn.mean.copy_(rnd((C,), torch.float32, 19, 0.4))
+    w2 = rnd((64, C, 3, 3), torch.float32, 17, 0.1)
+    H2 = H1 - 2
+    un = _nhwc(u).contiguous()
+    w2g = S._conv2_weight(w2, dtype)
+    u2 = torch.empty((Fr * H2 * H2, 64), dtype=dtype, device=DEV)
+    _lib.check(L.istvt_conv2_fwd(un.data_ptr(), bn.ptr(), w2g.data_ptr(), u2.data_ptr(), Fr, H1, H1, ops._stream()), 'conv2')
+    zd = ((u.float() - bn.mean.view(1, C, 1, 1)) * bn.scale.view(1, C, 1, 1) + bn.beta.view(1, C, 1, 1)).double().requires_grad_(True)
+    ad = torch.relu(zd)
+    aq = ad + (ad.detach().to(dtype).double() - ad.detach())
+    w2d = w2.to(dtype).double().requires_grad_(True)
+    r2 = torch.nn.functional.conv2d(aq, w2d)
+    e = max(e, relerr(u2, _nhwc(r2)))
+    g2 = rnd((Fr, 64, H2, H2), dtype, 18)
+    r2.backward(g2.double())
+    g2n = _nhwc(g2).contiguous()
+    dz = torch.empty_like(un)
+    _lib.check(L.istvt_conv2_dgrad(g2n.data_ptr(), w2g.data_ptr(), un.data_ptr(), bn.ptr(), dz.data_ptr(), Fr, H1, H1,
+                                   ops._stream()), 'conv2 dgrad')
+    e = max(e, relerr(dz, _nhwc(zd.grad)))
+    dW2 = torch.zeros((64, 288), dtype=torch.float32, device=DEV)
+    slabs = torch.empty((L.istvt_conv2_wgrad_slabs(), 64 * 288), dtype=torch.float32, device=DEV)
+    _lib.check(L.istvt_conv2_wgrad(g2n.data_ptr(), un.data_ptr(), bn.ptr(), slabs.data_ptr(), dW2.data_ptr(), Fr, H1, H1,
+                                   ops._stream()), 'conv2 wgrad')
+    e = max(e, relerr(dW2.view(64, 3, 3, C).permute(0, 3, 1, 2), w2d.grad))
+    return e, TOL[dtype]
+
+
 _base2_all_checks = all_checks
 
 
@@ -567,4 +613,6 @@ def all_checks():  # noqa: F811
             out.append(('stem_dwepi_%s_%s' % (case, tag), lambda dt=dt, case=case: dwconv_epilogue_check(dt, case)))
             out.append(('stem_dwepi_big_%s_%s' % (case, tag), lambda dt=dt, case=case: dwconv_epilogue_check(dt, case, 2, 45, 45, 64)))
         out.append(('stem_im2col_%s' % tag, lambda dt=dt: im2col_check(dt)))
+        out.append(('stem_convdense_%s' % tag, lambda dt=dt: conv_dense_check(dt)))
+        out.append(('stem_convdense_odd_%s' % tag, lambda dt=dt: conv_dense_check(dt, 3, 77)))
     return out
