@@ -196,3 +196,35 @@ def test_fused_bucket_accumulation_matches_autograd():
         grads.append(bucket.flat.clone())
     assert float(grads[0].norm()) > 0
     assert relerr(grads[1], grads[0]) < 1e-5
+
+
+def test_side_stream_weight_gradients_match_single_stream():
+    """Weight-gradient GEMMs enqueued on the side stream (joined by the end-of-backward callback) give the gradients
+    of the single-stream order, step after step, with the caching allocator recycling dy / activation blocks."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import functional as Fn, parallel
+    R, p, x, labels, grid = _oracle_case(2, 4, 96, 2)
+    results = []
+    try:
+        for overlap in (False, True):
+            Fn.set_wgrad_overlap(overlap)
+            model = _hip_model(p, 4, grid, 2)
+            live = parallel.live_named_parameters(model)
+            bucket = parallel.GradBucket([q for _, q in live], fuse_accumulate=True)
+            snaps = []
+            for it in range(3):
+                bucket.zero()
+                out = model(x.cuda() * (1.0 + 0.25 * it))
+                torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+                # no explicit synchronisation: the clone is ordered after the join on the current stream
+                snaps.append(bucket.flat.clone())
+            results.append(snaps)
+            if overlap:
+                assert Fn._overlap['streams'], 'the side stream was never used'
+                assert not Fn._overlap['pending'], 'end-of-backward join did not run'
+    finally:
+        Fn.set_wgrad_overlap(True)
+    for a, b in zip(*results):
+        assert float(a.norm()) > 0
+        assert relerr(b, a) < 1e-5
