@@ -36,6 +36,8 @@ SIGNATURES = {
     'istvt_bn_bwd_apply': [P, P, P, P, P, P, P, P, P, L, I, I, P],
     'istvt_im2col_conv1': [P, P, I, I, I, P],
     'istvt_conv1_fwd': [P, P, P, I, I, I, P],
+    'istvt_conv1_wgrad': [P, P, P, P, I, I, I, P],
+    'istvt_conv1_wgrad_slabs': [],
     'istvt_conv2_fwd': [P, P, P, P, I, I, I, P],
     'istvt_conv2_dgrad': [P, P, P, P, P, I, I, I, P],
     'istvt_conv2_wgrad': [P, P, P, P, P, I, I, I, P],

@@ -307,6 +307,77 @@ __global__ __launch_bounds__(256) void conv2_wgrad_kernel(const bf16_t* __restri
             for (int i = 0; i < 4; ++i) out[(16 * wave + 4 * g + i) * 288 + tap * 32 + 16 * ct + r] = acc[tap][ct][i];
 }
 
+// ------------------------------------------------------------------------------------------ conv1 weight gradient
+// dW1[co][k] = sum_px du1[px][co] * patch[px][k], k = (ci, dy, dx) as conv1.weight stores it (27, padded to 32).
+// One chunk = one output row (Wo <= 128 pixels).  Staged per chunk: dimg [128 px][32 co] (the row of du1) and pimg
+// [128 px][32 k] (the im2col patches of that row, gathered from the fp32 clip and rounded to bf16 -- the rounding the
+// im2col + GEMM path applies); wave (mt, nt) owns the 16 x 16 tile (co tile mt, k tile nt): four k-steps of 32 pixels.
+constexpr int C1_PX = 128;
+constexpr int C1_PITCH = 32 * 2 + 16;
+
+template <typename TD>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const TD* __restrict__ du1, const float* __restrict__ x,
+                                                          float* __restrict__ slabs, int S, int Ho, int Wo, int nrows) {
+    __shared__ __attribute__((aligned(16))) char dimg[C1_PX * C1_PITCH];
+    __shared__ __attribute__((aligned(16))) char pimg[C1_PX * C1_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int mt = wave >> 1, nt = wave & 1;
+    const int ppx = tid >> 1, pk0 = (tid & 1) * 16;          // patch role: pixel, first of 16 k
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 dreg[2];
+    float xreg[16];
+    auto gload = [&](int row) {
+        const int yo = row % Ho;
+        const long f = row / Ho;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                        // 128 px x 4 pieces of 8 channels
+            const int i = tid + 256 * k;
+            const int px = i >> 2, pc = i & 3;
+            dreg[k] = zero_frag();
+            if (px < Wo) {
+                float v[8];
+                load8(du1 + ((f * Ho + yo) * Wo + px) * 32 + pc * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dreg[k][j] = (bf16_t)v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = pk0 + j;                           // (ci, dy, dx)
+            const int ci = k / 9, dy = (k % 9) / 3, dx = k % 3;
+            xreg[j] = 0.f;
+            if (k < 27 && ppx < Wo) xreg[j] = x[((f * 3 + ci) * S + 2 * yo + dy) * S + 2 * ppx + dx];
+        }
+    };
+    int row = blockIdx.x;
+    if (row < nrows) gload(row);
+    for (; row < nrows; row += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            *reinterpret_cast<bf16x8*>(dimg + (i >> 2) * C1_PITCH + (i & 3) * 16) = dreg[k];
+        }
+        {
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p0[j] = (bf16_t)xreg[j]; p1[j] = (bf16_t)xreg[8 + j]; }
+            *reinterpret_cast<bf16x8*>(pimg + ppx * C1_PITCH + pk0 * 2) = p0;
+            *reinterpret_cast<bf16x8*>(pimg + ppx * C1_PITCH + pk0 * 2 + 16) = p1;
+        }
+        __syncthreads();
+        if (row + (int)gridDim.x < nrows) gload(row + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < C1_PX / 32; ++ks)
+            acc = mma16(tr_frag(dimg, C1_PITCH, 32 * ks + 8 * g, 16 * mt, r),
+                        tr_frag(pimg, C1_PITCH, 32 * ks + 8 * g, 16 * nt, r), acc);
+        __syncthreads();
+    }
+    float* out = slabs + (long)blockIdx.x * 32 * 32;         // rows co = 16 mt + 4g + i, column k = 16 nt + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(16 * mt + 4 * g + i) * 32 + 16 * nt + r] = acc[i];
+}
+
 // dw[i] += sum over slabs: blockIdx.y takes every gridDim.y-th slab
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, int n,
                                                           float* __restrict__ dw) {
@@ -379,5 +450,27 @@ extern "C" int istvt_conv2_wgrad(const void* du2, const void* u1, const float* b
     const int n = 64 * 288;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256, grid < 16 ? grid : 16), dim3(256), 0, stream, slabs,
                        grid, n, dw);
+    return istvt_check_launch();
+}
+
+// conv1 weight gradient: du1 [frames*Ho*Wo][32] (dtype), x float [frames][3][S][S] -> dw float [32][32] +=, column
+// k = ci*9 + dy*3 + dx (the order of conv1.weight[co]; columns 27..31 stay untouched zeros of the patches);
+// slabs = caller-owned float workspace of istvt_conv1_wgrad_slabs() * 1024 elements.  Needs Wo <= 128 (S <= 257).
+extern "C" int istvt_conv1_wgrad_slabs() { return 1024; }
+
+extern "C" int istvt_conv1_wgrad(const void* du1, const float* x, float* slabs, float* dw, int Fr, int S, int dtype,
+                                 hipStream_t stream) {
+    if (Fr <= 0 || S < 3 || !slabs) return ISTVT_ERR_SHAPE;
+    const int Ho = (S - 3) / 2 + 1;
+    if (Ho > C1_PX) return ISTVT_ERR_SHAPE;
+    const long nrows = (long)Fr * Ho;
+    if (nrows > 0x7fffffffL) return ISTVT_ERR_SHAPE;
+    const int cap = istvt_conv1_wgrad_slabs();
+    const int grid = nrows < cap ? (int)nrows : cap;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), dim3(grid), dim3(256), 0, stream, (const T*)du1, x,
+                                             slabs, S, Ho, Ho, (int)nrows));
+    int rc = istvt_check_launch();
+    if (rc != ISTVT_OK) return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(4, grid < 16 ? grid : 16), dim3(256), 0, stream, slabs, grid, 1024, dw);
     return istvt_check_launch();
 }

@@ -360,10 +360,20 @@ class StemFn(Function):
         du1, dg, db = bn_backward(dz1, sv['u1'], sv['bn1'], P['bn1.weight'], M1, 32)
         grads['bn1.weight'], grads['bn1.bias'] = dg, db
         del dz1
-        col1 = torch.empty((M1, 32), dtype=dtype, device=du1.device)
-        _lib.check(L.istvt_im2col_conv1(sv['x'].data_ptr(), col1.data_ptr(), Fr, S, dtc, _stream()), 'istvt_im2col_conv1')
-        dW1 = ops.linear_wgrad(du1, col1)                                    # [32][32]
-        grads['conv1.weight'] = dW1[:, :27].reshape(32, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        if dtype == torch.bfloat16 and H1 <= 128:
+            du1 = du1.contiguous()
+            dW1 = torch.zeros((32, 32), dtype=torch.float32, device=du1.device)      # [co][(ci,dy,dx) + 5 unused]
+            slabs = torch.empty((L.istvt_conv1_wgrad_slabs(), 1024), dtype=torch.float32, device=du1.device)
+            _lib.check(L.istvt_conv1_wgrad(du1.data_ptr(), sv['x'].data_ptr(), slabs.data_ptr(), dW1.data_ptr(), Fr, S, dtc,
+                                           _stream()), 'istvt_conv1_wgrad')
+            grads['conv1.weight'] = dW1[:, :27].reshape(32, 3, 3, 3).contiguous()
+            del slabs
+        else:
+            col1 = torch.empty((M1, 32), dtype=dtype, device=du1.device)
+            _lib.check(L.istvt_im2col_conv1(sv['x'].data_ptr(), col1.data_ptr(), Fr, S, dtc, _stream()), 'istvt_im2col_conv1')
+            dW1 = ops.linear_wgrad(du1, col1)                                    # [32][(dy,dx,ci) + 5 zero columns]
+            grads['conv1.weight'] = dW1[:, :27].reshape(32, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+            del col1
         dx = None
         if ctx.need_dx:
             dcol1 = ops.linear_dgrad(du1, sv['w1'])

@@ -147,6 +147,12 @@ int istvt_col2im3x3(const void* dcol, const void* u, const float* bnp, void* dz,
  * relu'(bn1(u1)); wgrad: dw float [64][(dy,dx,ci)] += sum over pixels, slabs = caller-owned float workspace of
  * istvt_conv2_wgrad_slabs() * 64 * 288 elements. */
 int istvt_conv1_fwd(const float* x, const float* w, void* u1, int frames, int S, int dtype, istvt_stream_t stream);
+/* conv1 weight gradient: du1 [frames*Ho*Wo][32] (dtype; rounded to bf16 for the MFMA), x as above ->
+ * dw float [32][32] +=, column k = ci*9 + dy*3 + dx (conv1.weight's own order; columns 27..31 unused);
+ * slabs = caller-owned float workspace of istvt_conv1_wgrad_slabs() * 1024 elements.  Ho <= 128. */
+int istvt_conv1_wgrad(const void* du1, const float* x, float* slabs, float* dw, int frames, int S, int dtype,
+                      istvt_stream_t stream);
+int istvt_conv1_wgrad_slabs(void);
 int istvt_conv2_fwd(const void* u1, const float* bnp, const void* w, void* u2, int frames, int H, int W,
                     istvt_stream_t stream);
 int istvt_conv2_dgrad(const void* du2, const void* w, const void* u1, const float* bnp, void* dz1, int frames, int H,

@@ -571,6 +571,17 @@ def conv_dense_check(dtype, Fr=2, S_=33):
     e = relerr(u1, _nhwc(r1))
     if dtype != torch.bfloat16:
         return e, TOL[dtype]
+    g1 = rnd((Fr, 32, H1, H1), dtype, 13)
+    xq = x.to(dtype).double()                       # the patches are rounded to the storage dtype, as im2col does
+    w1d = w1.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xq, w1d, None, 2, 0).backward(g1.double())
+    g1n = _nhwc(g1).contiguous()
+    dW1 = torch.zeros((32, 32), dtype=torch.float32, device=DEV)
+    slabs1 = torch.empty((L.istvt_conv1_wgrad_slabs(), 1024), dtype=torch.float32, device=DEV)
+    _lib.check(L.istvt_conv1_wgrad(g1n.data_ptr(), x.data_ptr(), slabs1.data_ptr(), dW1.data_ptr(), Fr, S_,
+                                   ops._DT[dtype], ops._stream()), 'conv1 wgrad')
+    e = max(e, relerr(dW1[:, :27].reshape(32, 3, 3, 3), w1d.grad))
+    assert float(dW1[:, 27:].abs().max()) == 0.0
     C = 32
     u = rnd((Fr, C, H1, H1), dtype, 14)
     bn = S.BNState(C, DEV)
