@@ -17,7 +17,7 @@ SIGNATURES = {
     'istvt_gemm': [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, I, I, I, F, I, P],
     'istvt_layernorm_fwd': [P, L, P, P, P, L, P, P, L, I, F, I, P],
     'istvt_layernorm_fwd_diff': [P, L, P, P, P, L, P, L, P, P, I, I, I, I, F, I, P],
-    'istvt_layernorm_bwd': [P, L, P, L, P, L, P, P, P, P, L, P, L, P, P, L, I, I, I, I, P],
+    'istvt_layernorm_bwd': [P, L, P, L, P, L, P, P, P, P, L, P, L, P, P, P, L, I, I, I, I, P],
     'istvt_attn_spatial_fwd': [P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_bwd': [P, P, P, P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_fwd_fp8': [P, P, P, I, I, I, I, F, I, P],

@@ -152,12 +152,15 @@ template <typename T> struct LnBwdRow {
     bool sub;          // temporal variant: subtract dy2 of the next frame
 };
 
-template <typename T>
+// DCOL: also accumulate the column sums of dx (in fp32, before rounding) into dcol -- dx is the output gradient of the
+// Linear that produced this LayerNorm's input, so this IS that Linear's bias gradient and saves its own pass over dx.
+template <typename T, bool DCOL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const float* __restrict__ gamma,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dcol, long M,
                                                      int D, int F, int P, long ld_dy, long ld_dy2, long ld_x, long ld_res,
                                                      long ld_dx) {
     __shared__ float red[2][4][LN_MAXCH * 64 * 8];
@@ -166,11 +169,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
     const long nwaves = (long)gridDim.x * 4;
     float gm[LN_MAXCH][8];
     ln_row_load<float>(gamma, D, lane, gm);
-    float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+    float ag[LN_MAXCH][8], ab[LN_MAXCH][8], ac[DCOL ? LN_MAXCH : 1][8];
 #pragma unroll
     for (int c = 0; c < LN_MAXCH; ++c)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; if (DCOL) ac[c][i] = 0.f; }
     const long N = (long)F * P;
     bool on[LN_MAXCH];
 #pragma unroll
@@ -249,6 +252,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] += rr[i];
                 }
+                if (DCOL) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ac[c][i] += o[i];
+                }
                 store8(dx + m * ld_dx + e, o);
             }
         }
@@ -270,6 +277,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
             for (int w = 0; w < 4; ++w) { a += red[0][w][col]; b += red[1][w][col]; }
             atomicAdd(dgamma + col, a);
             atomicAdd(dbeta + col, b);
+        }
+    }
+    if (DCOL) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[0][wid][(c * 64 + lane) * 8 + i] = ac[c][i];
+        __syncthreads();
+        for (int col = threadIdx.x; col < LN_MAXCH * 512; col += 256) {
+            if (col < D) atomicAdd(dcol + col, (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]));
         }
     }
 }
@@ -301,11 +319,12 @@ extern "C" int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* ga
     return istvt_check_launch();
 }
 
-// dy2 == null: plain LayerNorm backward (F, P ignored).  dres may be null.  dgamma/dbeta accumulate.
+// dy2 == null: plain LayerNorm backward (F, P ignored).  dres may be null.  dgamma/dbeta accumulate; dcol (may be
+// null) accumulates the column sums of dx.
 extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, long ld_dy2, const void* x, long ld_x,
                                    const float* mean, const float* rstd, const float* gamma, const void* dres,
-                                   long ld_res, void* dx, long ld_dx, float* dgamma, float* dbeta, long M, int D, int F,
-                                   int P, int dtype, hipStream_t stream) {
+                                   long ld_res, void* dx, long ld_dx, float* dgamma, float* dbeta, float* dcol, long M,
+                                   int D, int F, int P, int dtype, hipStream_t stream) {
     if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0) return ISTVT_ERR_SHAPE;
     if (ld_dy < D || ld_x < D || ld_dx < D || ld_dy % 8 || ld_x % 8 || ld_dx % 8) return ISTVT_ERR_SHAPE;
     if ((dy2 && (ld_dy2 < D || ld_dy2 % 8)) || (dres && (ld_res < D || ld_res % 8))) return ISTVT_ERR_SHAPE;
@@ -313,9 +332,15 @@ extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, 
     if (!dy2) { F = 1; P = 1; }
     long blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3((int)blocks), dim3(256), 0, stream,
-                                             (const T*)dy, (const T*)dy2, (const T*)x, mean, rstd, gamma,
-                                             (const T*)dres, (T*)dx, dgamma, dbeta, M, D, F, P, ld_dy, ld_dy2, ld_x,
-                                             ld_res, ld_dx));
+    if (dcol)
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, true>), dim3((int)blocks), dim3(256), 0, stream,
+                                                 (const T*)dy, (const T*)dy2, (const T*)x, mean, rstd, gamma,
+                                                 (const T*)dres, (T*)dx, dgamma, dbeta, dcol, M, D, F, P, ld_dy, ld_dy2,
+                                                 ld_x, ld_res, ld_dx));
+    else
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, false>), dim3((int)blocks), dim3(256), 0, stream,
+                                                 (const T*)dy, (const T*)dy2, (const T*)x, mean, rstd, gamma,
+                                                 (const T*)dres, (T*)dx, dgamma, dbeta, dcol, M, D, F, P, ld_dy, ld_dy2,
+                                                 ld_x, ld_res, ld_dx));
     return istvt_check_launch();
 }

@@ -30,39 +30,63 @@ def _target(p):
     return z, z
 
 
+class BiasSink:
+    """Names the bias parameter of the nn.Linear whose output a LayerNorm normalises.  That Linear's bias gradient is
+    the column sum of the LayerNorm's input gradient, so the LayerNorm backward kernel accumulates it on the way
+    (ops.layernorm_bwd(dcol=...)) and the Linear, called with defer_bias=True, skips its own pass over dy.  Only valid
+    when the gradient lands straight in ``bias.grad`` (GradBucket(fuse_accumulate=True)): see ``usable``."""
+    __slots__ = ('bias',)
+
+    def __init__(self, bias):
+        self.bias = bias
+
+    @staticmethod
+    def usable(bias) -> bool:
+        return (bias is not None and torch.is_grad_enabled() and bias.requires_grad
+                and getattr(bias, '_istvt_fused_grad', False) and bias.grad is not None)
+
+    def buffer(self):
+        return self.bias.grad
+
+
 class LayerNormFn(Function):
     """nn.LayerNorm over the last dim (reference module.py:15-21).  fork=True also returns the input itself: a
     caller that uses x both as the LayerNorm input and as a residual takes the second output for the residual, and
     the gradient arriving through it is added inside the LayerNorm backward kernel (no separate add pass)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fork=False):
+    def forward(ctx, x, gamma, beta, eps, fork=False, sink=None):
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, pad=True)
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.set_materialize_grads(False)
+        ctx.sink = sink
         return (y, x.view_as(x)) if fork else y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, dres=None):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dcol = ctx.sink.buffer() if ctx.sink is not None else None
         if dy is None:                       # only the pass-through output was used
-            return dres, None, None, None, None
+            if dcol is not None and dres is not None:
+                ops.colsum(dres.reshape(-1, dres.shape[-1]), out=dcol)
+            return dres, None, None, None, None, None
         dg, rg = _target(gamma)
         db, rb = _target(beta)
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True)
-        return dx, rg, rb, None, None
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True, dcol=dcol)
+        return dx, rg, rb, None, None, None
 
 
 class LayerNormDiffFn(Function):
     """LayerNorm that also returns the frame difference of its output (module.py:193); fork as in LayerNormFn."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, B, F, P, fork=False):
+    def forward(ctx, x, gamma, beta, eps, B, F, P, fork=False, sink=None):
         y, diff, mean, rstd = ops.layernorm_fwd_diff(x, gamma, beta, eps, B, F, P, pad=True)
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.geom = (F, P)
         ctx.set_materialize_grads(False)
+        ctx.sink = sink
         return (y, diff, x.view_as(x)) if fork else (y, diff)
 
     @staticmethod
@@ -74,8 +98,9 @@ class LayerNormDiffFn(Function):
         db, rb = _target(beta)
         if dy is None:
             dy = torch.zeros_like(ddiff if ddiff is not None else x)
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, dres=dres, F=F, P=P, pad=True)
-        return dx, rg, rb, None, None, None, None, None
+        dcol = ctx.sink.buffer() if ctx.sink is not None else None
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, dres=dres, F=F, P=P, pad=True, dcol=dcol)
+        return dx, rg, rb, None, None, None, None, None, None
 
 
 class FrameDiffFn(Function):
@@ -154,11 +179,13 @@ class LinearFn(Function):
     """y = x W^T (+ b) (+ residual) on [M, K] inputs (nn.Linear, module.py:74,77,182,183,186)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual):
+    def forward(ctx, x, weight, bias, residual, defer_bias=False):
+        """defer_bias: the LayerNorm that consumes y accumulates the bias gradient (BiasSink); skip it here."""
         w = ops.weight_as(weight, x.dtype, pad=True)
         y = ops.linear_fwd(x, w, bias, residual, pad=True)
         ctx.save_for_backward(x, weight, bias)
         ctx.has_res = residual is not None
+        ctx.defer_bias = bool(defer_bias)
         return y
 
     @staticmethod
@@ -168,20 +195,21 @@ class LinearFn(Function):
         w = ops.weight_as(weight, dy.dtype, pad=True)       # the forward's operand copy: W^T is derived from it once
         dx = ops.linear_dgrad(dy, w, pad=True) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dy, x, weight) if ctx.needs_input_grad[1] else None
-        db = _bgrad(dy, bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        db = _bgrad(dy, bias) if (bias is not None and ctx.needs_input_grad[2] and not ctx.defer_bias) else None
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres
+        return dx, dw, db, dres, None
 
 
 class FeedForwardFn(Function):
     """Linear -> exact GELU -> Linear (+ residual) (FeedForward, module.py:23-34)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual):
+    def forward(ctx, x, w1, b1, w2, b2, residual, defer_bias=False):
         u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True)
         y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype, pad=True), b2, residual, pad=True)
         ctx.save_for_backward(x, u, g, w1, b1, w2, b2)
         ctx.has_res = residual is not None
+        ctx.defer_bias = bool(defer_bias)           # b2's gradient comes from the next LayerNorm's backward (BiasSink)
         return y
 
     @staticmethod
@@ -190,11 +218,11 @@ class FeedForwardFn(Function):
         x, u, g, w1, b1, w2, b2 = ctx.saved_tensors
         du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True)       # (dy W2) * gelu'(u)
         dw2 = _wgrad(dy, g, w2)
-        db2 = _bgrad(dy, b2)
+        db2 = None if ctx.defer_bias else _bgrad(dy, b2)
         dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype, pad=True), pad=True) if ctx.needs_input_grad[0] else None
         dw1 = _wgrad(du, x, w1)
         db1 = _bgrad(du, b1)
-        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
 
 
 class SpatialAttnFn(Function):
@@ -271,8 +299,8 @@ class TakeClsFn(Function):
         return dx.view(B, F * P, D), None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, fork=False):
-    return LayerNormFn.apply(x, gamma, beta, eps, fork)
+def layer_norm(x, gamma, beta, eps=1e-5, fork=False, sink=None):
+    return LayerNormFn.apply(x, gamma, beta, eps, fork, sink)
 
 
 def linear(x: Tensor, weight: Tensor, bias=None, residual=None) -> Tensor:

@@ -41,20 +41,24 @@ class PreNorm(nn.Module):
         #                       a caller that adds x as a residual LATER gets that gradient summed inside the
         #                       LayerNorm backward kernel instead of a separate add pass;
         #   residual='input' -> fn(norm(x), residual=x) with the same routing.
+        #   sink=BiasSink(b) -> x is the output of the nn.Linear with bias b (called with defer_bias=True): its bias
+        #                       gradient, the column sum of this LayerNorm's input gradient, is accumulated by the
+        #                       LayerNorm backward kernel instead of a separate pass.
         fork = kwargs.pop('fork', False)
+        sink = kwargs.pop('sink', None)
         own_res = isinstance(kwargs.get('residual'), str) and kwargs['residual'] == 'input'
         fused = getattr(self.fn, 'forward_prenorm', None)
         if fused is not None:           # temporal attention: LayerNorm + frame difference in one kernel
             if own_res:
                 raise NotImplementedError("residual='input' is not used with the temporal attention block")
-            return fused(x, self.norm, fork=fork, **kwargs)
+            return fused(x, self.norm, fork=fork, sink=sink, **kwargs)
         if fork or own_res:
-            y, xr = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, fork=True)
+            y, xr = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, fork=True, sink=sink)
             if own_res:
                 kwargs['residual'] = xr
             out = self.fn(y, **kwargs)
             return (out, xr) if fork else out
-        return self.fn(Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
+        return self.fn(Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, sink=sink), **kwargs)
 
 
 class FeedForward(nn.Module):
@@ -68,14 +72,14 @@ class FeedForward(nn.Module):
             nn.Dropout(dropout)
         )
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, defer_bias=False):
         fc1, fc2 = self.net[0], self.net[3]
         if self.training and (self.net[2].p > 0 or self.net[4].p > 0):
             raise NotImplementedError('FeedForward with dropout > 0 in training mode is not on the ISTVT hot path')
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         r2 = residual.reshape(-1, fc2.out_features) if residual is not None else None
-        y = Fn.FeedForwardFn.apply(x2, fc1.weight, fc1.bias, fc2.weight, fc2.bias, r2)
+        y = Fn.FeedForwardFn.apply(x2, fc1.weight, fc1.bias, fc2.weight, fc2.bias, r2, defer_bias)
         return y.view(*lead, fc2.out_features)
 
 
@@ -94,7 +98,7 @@ class SpatialOnlyAttention(nn.Module):
             nn.Dropout(dropout)
         )
 
-    def forward(self, x, hw=None, residual=None):
+    def forward(self, x, hw=None, residual=None, defer_bias=False):
         b, n, _ = x.shape
         hw = self.hw if hw is None else hw
         frames = _frames(n, hw, 'SpatialOnlyAttention')
@@ -104,7 +108,7 @@ class SpatialOnlyAttention(nn.Module):
         proj = self.to_out[0]
         plain = self.to_out[1].p == 0.0 or not self.training
         r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
-        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2).view(b, n, -1)
+        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2, defer_bias and plain).view(b, n, -1)
         if not plain:
             y = _dropout(self.to_out, y)
             if residual is not None:
@@ -127,33 +131,33 @@ class TemporalResidualAttention(nn.Module):
             nn.Dropout(dropout)
         )
 
-    def _attend(self, xn, diff, b, n, hw, frames, residual):
+    def _attend(self, xn, diff, b, n, hw, frames, residual, defer_bias=False):
         qk = Fn.LinearFn.apply(diff, self.to_qk.weight, None, None)
         v = Fn.LinearFn.apply(xn, self.to_v.weight, None, None)
         out = Fn.TemporalAttnFn.apply(qk, v, b, frames, hw, self.heads, self.dim_head)
         proj = self.to_out[0]
         plain = self.to_out[1].p == 0.0 or not self.training
         r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
-        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2).view(b, n, -1)
+        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2, defer_bias and plain).view(b, n, -1)
         if not plain:
             y = _dropout(self.to_out, y)
             if residual is not None:
                 y = y + residual
         return y
 
-    def forward(self, x, hw=None, residual=None):
+    def forward(self, x, hw=None, residual=None, defer_bias=False):
         b, n, d = x.shape
         hw = self.hw if hw is None else hw
         frames = _frames(n, hw, 'TemporalResidualAttention')
         x2 = x.reshape(b * n, d)
         diff = Fn.FrameDiffFn.apply(x2, b, frames, hw)
-        return self._attend(x2, diff, b, n, hw, frames, residual)
+        return self._attend(x2, diff, b, n, hw, frames, residual, defer_bias)
 
-    def forward_prenorm(self, x, norm, hw=None, residual=None, fork=False):
+    def forward_prenorm(self, x, norm, hw=None, residual=None, fork=False, sink=None, defer_bias=False):
         """PreNorm(self)(x): LayerNorm and the frame difference come out of one kernel."""
         b, n, d = x.shape
         hw = self.hw if hw is None else hw
         frames = _frames(n, hw, 'TemporalResidualAttention')
-        outs = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw, fork)
-        y = self._attend(outs[0], outs[1], b, n, hw, frames, residual)
+        outs = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw, fork, sink)
+        y = self._attend(outs[0], outs[1], b, n, hw, frames, residual, defer_bias)
         return (y, outs[2].view(b, n, d)) if fork else y

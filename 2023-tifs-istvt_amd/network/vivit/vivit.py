@@ -30,10 +30,24 @@ class STTransformer(nn.Module):
         # x = attn_s(attn_t(x)) + x ; x = ff(x) + x   (ONE residual around temporal-then-spatial,
         # vivit.py:99); both adds run in the epilogue of the block's last GEMM, and the residual's gradient is
         # summed inside the backward kernel of the LayerNorm that shares its input (PreNorm fork / 'input').
-        for attn_t, attn_s, ff in self.layers:
-            y_t, x_res = attn_t(x, hw=hw, fork=True)
-            x = attn_s(y_t, hw=hw, residual=x_res)
-            x = ff(x, residual='input')
+        # Bias gradients of the three output projections: each projection's output is normalised by the NEXT block's
+        # LayerNorm, whose backward kernel sums its input gradient over rows on the way (Fn.BiasSink) -- when the
+        # gradient buffers are the fused bucket and no dropout sits between the projection and the LayerNorm.
+        def sink_for(lin, drop):
+            plain = drop.p == 0.0 or not self.training
+            return Fn.BiasSink(lin.bias) if (plain and Fn.BiasSink.usable(lin.bias)) else None
+
+        prev = None                              # sink for the previous layer's FeedForward output bias
+        last = len(self.layers) - 1
+        for li, (attn_t, attn_s, ff) in enumerate(self.layers):
+            s_t = sink_for(attn_t.fn.to_out[0], attn_t.fn.to_out[1])
+            s_s = sink_for(attn_s.fn.to_out[0], attn_s.fn.to_out[1])
+            # the last FeedForward feeds the class-row LayerNorm only: it keeps its own bias-gradient pass
+            s_f = sink_for(ff.fn.net[3], ff.fn.net[4]) if li != last else None
+            y_t, x_res = attn_t(x, hw=hw, fork=True, sink=prev, defer_bias=s_t is not None)
+            x = attn_s(y_t, hw=hw, residual=x_res, sink=s_t, defer_bias=s_s is not None)
+            x = ff(x, residual='input', sink=s_s, defer_bias=s_f is not None)
+            prev = s_f
         if cls_of is not None:
             # DSTTr only reads row (b, frame 0, token 0) of the final LayerNorm (vivit.py:144-146): LayerNorm is
             # row-wise, so normalising just those rows is bit-identical and skips 99.9 % of the pass

@@ -376,7 +376,8 @@ def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: in
 
 def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
                   dy2: Optional[Tensor] = None, dres: Optional[Tensor] = None, F: int = 1, P: int = 1,
-                  pad: bool = False) -> Tensor:
+                  pad: bool = False, dcol: Optional[Tensor] = None) -> Tensor:
+    """dcol: float32 [D] buffer that receives (+=) the column sums of dx."""
     x2, ldx = rows(x)
     M, D = x2.shape
     dy, ld_dy = rows(_req(dy))
@@ -390,7 +391,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
     with prof('ln_bwd', ntens * M * D * x.element_size()):
         _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), ld_dy, _ptr(dy2), ld_dy2, x2.data_ptr(), ldx, mean.data_ptr(),
                                                   rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(),
-                                                  dx.stride(0) if M > 1 else D, dgamma.data_ptr(), dbeta.data_ptr(), M, D, F,
+                                                  dx.stride(0) if M > 1 else D, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dcol), M, D, F,
                                                   P, dtype_code(x), _stream()), 'istvt_layernorm_bwd')
     return dx if x.dim() == 2 else dx.view(*x.shape)
 

@@ -63,11 +63,12 @@ int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* gamma, const 
                              void* diff, long ldd, float* mean, float* rstd, int B, int F, int P, int D, float eps,
                              int dtype, istvt_stream_t stream);
 /* dy2 (may be NULL) = gradient w.r.t. diff; dres (may be NULL) = gradient arriving through the
- * residual connection, added to dx.  dgamma/dbeta accumulate. */
+ * residual connection, added to dx.  dgamma/dbeta accumulate.  dcol (may be NULL) accumulates the column sums of
+ * dx: the bias gradient of the nn.Linear whose output this LayerNorm normalises (module.py:30,77,186). */
 int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, long ld_dy2, const void* x, long ld_x,
                         const float* mean, const float* rstd, const float* gamma, const void* dres, long ld_res,
-                        void* dx, long ld_dx, float* dgamma, float* dbeta, long M, int D, int F, int P, int dtype,
-                        istvt_stream_t stream);
+                        void* dx, long ld_dx, float* dgamma, float* dbeta, float* dcol, long M, int D, int F, int P,
+                        int dtype, istvt_stream_t stream);
 
 /* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
  * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)'), out [BF*P][heads*dh],

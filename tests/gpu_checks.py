@@ -137,6 +137,12 @@ def layernorm(dtype, D=728, M=1003, pad=False):
         dres = padded(dres)                 # dy stays contiguous: the strides are independent
     dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres, pad=pad)
     e = max(relerr(y, ref), relerr(dx, xd.grad + dres.double()), relerr(dg, gd.grad), relerr(db, bd.grad))
+    # the same call with the fused column sums of dx (the preceding Linear's bias gradient): dx, dgamma, dbeta
+    # unchanged, dcol accumulates on top of what the buffer holds
+    dg2, db2, dcol = torch.zeros_like(g), torch.zeros_like(b), torch.ones((D,), dtype=torch.float32, device=DEV)
+    dx2 = ops.layernorm_bwd(dy, x, mean, rstd, g, dg2, db2, dres=dres, pad=pad, dcol=dcol)
+    e = max(e, relerr(dx2, dx), relerr(dg2, dg), relerr(db2, db),
+            relerr(dcol - 1.0, (xd.grad + dres.double()).sum(0)))
     return e, TOL[dtype]
 
 
@@ -160,8 +166,10 @@ def layernorm_diff(dtype, B=2, F=9, P=37, D=728, pad=False):
     dg, db = torch.zeros_like(g), torch.zeros_like(b)
     if pad:
         dy, dd = padded(dy), padded(dd)
-    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dy2=dd, F=F, P=P, pad=pad)
-    e = max(relerr(y, ry), relerr(diff, rdiff), relerr(dx, xd.grad), relerr(dg, gd.grad), relerr(db, bd.grad))
+    dcol = torch.zeros((D,), dtype=torch.float32, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dy2=dd, F=F, P=P, pad=pad, dcol=dcol)
+    e = max(relerr(y, ry), relerr(diff, rdiff), relerr(dx, xd.grad), relerr(dg, gd.grad), relerr(db, bd.grad),
+            relerr(dcol, xd.grad.sum(0)))
     return e, TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
 
 
