@@ -20,6 +20,7 @@
 //   sattn_bwd_dkv: one wavefront owns 32 keys; queries stream through LDS;
 //                  dV^T += dO^T P ; dK^T += Q^T dS
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 constexpr int CHUNK = 128;          // rows of an LDS image
@@ -48,6 +49,42 @@ __device__ __forceinline__ void stage_img(T* img, const T* __restrict__ src, lon
             float* p = (float*)(img + row * LDI + col);
             *reinterpret_cast<float4*>(p) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
             *reinterpret_cast<float4*>(p + 4) = make_float4(f.v[4], f.v[5], f.v[6], f.v[7]);
+        }
+    }
+}
+
+// the same copy split in two: global -> registers (issued a chunk ahead, in flight under the current chunk's MFMAs)
+// and registers -> LDS image
+template <typename T, int DH, int NTHR>
+struct StageRegs { typename Mma<T>::frag f[CHUNK * (DH / 8) / NTHR]; };
+template <typename T, int DH, int NTHR>
+__device__ __forceinline__ void stage_fetch(StageRegs<T, DH, NTHR>& rg, const T* __restrict__ src, long ld, int row0,
+                                            int nrows, int tid) {
+    constexpr int VPR = DH / 8;
+    constexpr int NV = CHUNK * VPR / NTHR;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + NTHR * i;
+        const int row = v / VPR, col = (v % VPR) * 8;
+        if (row0 + row < nrows) rg.f[i] = frag_load(src + (long)(row0 + row) * ld + col);
+        else rg.f[i] = Mma<T>::zero();
+    }
+}
+template <typename T, int DH, int NTHR>
+__device__ __forceinline__ void stage_commit(T* img, const StageRegs<T, DH, NTHR>& rg, int tid) {
+    constexpr int LDI = DH + IPAD;
+    constexpr int VPR = DH / 8;
+    constexpr int NV = CHUNK * VPR / NTHR;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + NTHR * i;
+        const int row = v / VPR, col = (v % VPR) * 8;
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<bf16x8*>(img + row * LDI + col) = rg.f[i];
+        } else {
+            float* p = (float*)(img + row * LDI + col);
+            *reinterpret_cast<float4*>(p) = make_float4(rg.f[i].v[0], rg.f[i].v[1], rg.f[i].v[2], rg.f[i].v[3]);
+            *reinterpret_cast<float4*>(p + 4) = make_float4(rg.f[i].v[4], rg.f[i].v[5], rg.f[i].v[6], rg.f[i].v[7]);
         }
     }
 }
@@ -101,7 +138,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // registers of a wavefront: 4 instead of 2 wavefronts per SIMD, whose softmax (VALU) and MFMA phases then overlap and
 // whose staging latencies hide each other (the kernel is bound by neither pipe: it waits).
 template <typename T, int DH, int U, bool FP8 = false>
-__global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+__global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         float* __restrict__ lse, int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
@@ -138,18 +175,18 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
         for (int dt = 0; dt < DT; ++dt) o[dt][u] = f32x4{0, 0, 0, 0};
     }
 
-    for (int c0 = 0; c0 < P; c0 += CHUNK) {
-        if (c0) __syncthreads();
-        stage_img<T, DH, 512 / U>(Kimg, kp, ld, c0, P, tid);
-        stage_img<T, DH, 512 / U>(Vimg, vp, ld, c0, P, tid);
-        __syncthreads();
-        if (!active) continue;
+    // One chunk of 128 keys.  TAIL = the chunk that holds the row end: keys >= P are masked and tiles wholly past P
+    // skipped there; every other chunk runs the lean straight-line form.  The softmax is the kernel's critical
+    // resource (vector ALU, the exponential at quarter rate): the row maximum is taken on the raw scores (c > 0)
+    // and the scale rides in the exponent's FMA.
+    auto chunk = [&](const int c0, auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
         f32x4 s[NT][U];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int u = 0; u < U; ++u) s[t][u] = f32x4{0, 0, 0, 0};
-            if (c0 + 16 * t < P) {
+            if (!TAIL || c0 + 16 * t < P) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     typename Mma<T>::frag kf = frag_load(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
@@ -172,12 +209,10 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int key = c0 + 16 * t + 4 * g + j;
-                    const float z = key < P ? s[t][u][j] * c : -INFINITY;
-                    s[t][u][j] = z;
-                    mx = fmaxf(mx, z);
+                    if (TAIL) s[t][u][j] = (c0 + 16 * t + 4 * g + j < P) ? s[t][u][j] : -INFINITY;
+                    mx = fmaxf(mx, s[t][u][j]);
                 }
-            mx = group_max(mx);
+            mx = group_max(mx) * c;
             const float m_new = fmaxf(m_run[u], mx);
             const float alpha = fast_exp2(m_run[u] - m_new);
             float sum = 0.f;
@@ -185,7 +220,7 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float pv = fast_exp2(s[t][u][j] - m_new);
+                    const float pv = fast_exp2(fmaf(s[t][u][j], c, -m_new));
                     s[t][u][j] = pv;
                     sum += pv;
                 }
@@ -198,7 +233,7 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
         // O^T += V^T P^T
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
-            if (c0 + 32 * ss < P) {
+            if (!TAIL || c0 + 32 * ss < P) {
                 typename Mma<T>::frag pf[U];
                 long p8[U];
 #pragma unroll
@@ -227,6 +262,22 @@ __global__ __launch_bounds__(512 / U) void sattn_fwd_kernel(const T* __restrict_
                 }
             }
         }
+    };
+    StageRegs<T, DH, 512 / U> kreg, vreg;
+    stage_fetch(kreg, kp, ld, 0, P, tid);
+    stage_fetch(vreg, vp, ld, 0, P, tid);
+    for (int c0 = 0; c0 < P; c0 += CHUNK) {
+        if (c0) __syncthreads();
+        stage_commit(Kimg, kreg, tid);
+        stage_commit(Vimg, vreg, tid);
+        __syncthreads();
+        if (c0 + CHUNK < P) {                       // next chunk's rows: in flight under this chunk's MFMAs
+            stage_fetch(kreg, kp, ld, c0 + CHUNK, P, tid);
+            stage_fetch(vreg, vp, ld, c0 + CHUNK, P, tid);
+        }
+        if (!active) continue;
+        if (c0 + CHUNK > P) chunk(c0, std::true_type{});
+        else chunk(c0, std::false_type{});
     }
     if (!active) return;
 #pragma unroll
@@ -298,7 +349,9 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
         }
         dl[u] = group_sum(part);
         const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
-        lq[u] = st.x; li[u] = st.y;
+        // exponent offset with 1/rowsum folded in: p = exp2(s c - (max - log2(1/sum))); rows past P have 1/sum = 0 ->
+        // offset +inf -> p = 0
+        lq[u] = st.x - __builtin_amdgcn_logf(st.y); li[u] = st.y;
         if (q < P && g == 0) delta[((long)bf * P + q) * heads + h] = dl[u];
     }
 
@@ -308,12 +361,20 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
 #pragma unroll
         for (int u = 0; u < U; ++u) dq[dt][u] = f32x4{0, 0, 0, 0};
 
+    StageRegs<T, DH, 512 / U> kreg, vreg;
+    stage_fetch(kreg, kp, ld, 0, P, tid);
+    stage_fetch(vreg, vp, ld, 0, P, tid);
     for (int c0 = 0; c0 < P; c0 += CHUNK) {
         if (c0) __syncthreads();
-        stage_img<T, DH, 512 / U>(Kimg, kp, ld, c0, P, tid);
-        stage_img<T, DH, 512 / U>(Vimg, vp, ld, c0, P, tid);
+        stage_commit(Kimg, kreg, tid);
+        stage_commit(Vimg, vreg, tid);
         __syncthreads();
+        if (c0 + CHUNK < P) {
+            stage_fetch(kreg, kp, ld, c0 + CHUNK, P, tid);
+            stage_fetch(vreg, vp, ld, c0 + CHUNK, P, tid);
+        }
         if (!active) continue;
+        const bool tail = c0 + CHUNK > P;
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss >= P) continue;
@@ -338,9 +399,9 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
                 for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int key = c0 + 32 * ss + 16 * tt + 4 * g + j;
-                        const float pv = key < P ? fast_exp2(s[tt][u][j] * c - lq[u]) * li[u] : 0.f;
-                        s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]) * scale;       // dS^T
+                        float pv = fast_exp2(fmaf(s[tt][u][j], c, -lq[u]));
+                        if (tail && c0 + 32 * ss + 16 * tt + 4 * g + j >= P) pv = 0.f;
+                        s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]);               // dS^T / scale (applied to dQ below)
                     }
             }
             typename Mma<T>::frag dsf[U];
@@ -362,7 +423,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
         T* dqp = dqkv + ((long)bf * P + q) * ld + h * DH;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            float v[4] = {dq[dt][u][0], dq[dt][u][1], dq[dt][u][2], dq[dt][u][3]};
+            float v[4] = {dq[dt][u][0] * scale, dq[dt][u][1] * scale, dq[dt][u][2] * scale, dq[dt][u][3] * scale};
             store4(dqp + 16 * dt + 4 * g, v);
         }
     }
@@ -377,7 +438,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                                                             int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
-    __shared__ __attribute__((aligned(16))) float stat[3][CHUNK];
+    __shared__ __attribute__((aligned(16))) float stat[2][CHUNK];
     T* Qimg = smem;
     T* Dimg = smem + CHUNK * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
@@ -409,19 +470,30 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
 #pragma unroll
         for (int kt = 0; kt < U; ++kt) { dk[dt][kt] = f32x4{0, 0, 0, 0}; dv[dt][kt] = f32x4{0, 0, 0, 0}; }
 
-    for (int c0 = 0; c0 < P; c0 += CHUNK) {
-        if (c0) __syncthreads();
-        stage_img<T, DH, 512 / U>(Qimg, qp, ld, c0, P, tid);
-        stage_img<T, DH, 512 / U>(Dimg, dop, inner, c0, P, tid);
+    StageRegs<T, DH, 512 / U> qreg, dreg;
+    float2 streg = make_float2(0.f, 0.f);
+    float dlreg = 0.f;
+    auto fetch = [&](int c0) {
+        stage_fetch(qreg, qp, ld, c0, P, tid);
+        stage_fetch(dreg, dop, (long)inner, c0, P, tid);
         if (tid < CHUNK) {
             const int q = c0 + tid;
-            const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h]
-                                    : make_float2(0.f, 0.f);        // 1/l = 0 masks padded query rows
-            stat[0][tid] = st.x;
-            stat[2][tid] = st.y;
-            stat[1][tid] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
+            streg = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h]
+                          : make_float2(0.f, 0.f);                  // 1/l = 0 masks padded query rows
+            dlreg = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < P; c0 += CHUNK) {
+        if (c0) __syncthreads();
+        stage_commit(Qimg, qreg, tid);
+        stage_commit(Dimg, dreg, tid);
+        if (tid < CHUNK) {
+            stat[0][tid] = streg.x - __builtin_amdgcn_logf(streg.y);    // exponent offset incl. log2(1/sum); +inf for padding
+            stat[1][tid] = dlreg;
         }
         __syncthreads();
+        if (c0 + CHUNK < P) fetch(c0 + CHUNK);
         if (!active) continue;
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
@@ -446,16 +518,14 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                 const int qb = 32 * ss + 16 * tt + 4 * g;
                 const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][qb]);
                 const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][qb]);
-                const float4 i4 = *reinterpret_cast<const float4*>(&stat[2][qb]);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-                const float iv[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll
                 for (int kt = 0; kt < U; ++kt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float pv = fast_exp2(s[tt][kt][j] * c - lv[j]) * iv[j];
+                        const float pv = fast_exp2(fmaf(s[tt][kt][j], c, -lv[j]));
                         s[tt][kt][j] = pv;                                         // P
-                        dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]) * scale;     // dS
+                        dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]);             // dS / scale (applied to dK below)
                     }
             }
             typename Mma<T>::frag pf[U], dsf[U];
@@ -482,7 +552,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
         T* dvp = dqkv + ((long)bf * P + key) * ld + 2 * inner + h * DH;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            float a[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
+            float a[4] = {dk[dt][kt][0] * scale, dk[dt][kt][1] * scale, dk[dt][kt][2] * scale, dk[dt][kt][3] * scale};
             float b[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
             store4(dkp + 16 * dt + 4 * g, a);
             store4(dvp + 16 * dt + 4 * g, b);
