@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--attn-fp8', action='store_true', help='fp8 (e4m3) operands in the spatial-attention MFMAs (configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--eval', action='store_true',
+                    help='SURVEY 8(f) row 1: model.eval() + no_grad forward only (train_CNN.py:837-944); a different metric')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
     return ap.parse_args()
@@ -117,7 +119,13 @@ def main():
     if a.no_wgrad_overlap:
         Fn.set_wgrad_overlap(False)
 
+    if a.eval:
+        model.eval()
+
     def step(reduce=True):
+        if a.eval:
+            with torch.no_grad():
+                return model(x).sum()
         bucket.zero()
         logits = model(x)
         loss = crit(logits.view(-1), labels)
@@ -214,7 +222,8 @@ def main():
         clips = world * a.batch * a.steps
         value = clips / elapsed
         out = {
-            'metric': 'clips/sec (BxTx3x224x224 fwd+bwd)', 'value': round(value, 3), 'unit': 'clips/s',
+            'metric': 'clips/sec (BxTx3x224x224 forward, eval mode)' if a.eval else 'clips/sec (BxTx3x224x224 fwd+bwd)',
+            'value': round(value, 3), 'unit': 'clips/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if dtype == torch.bfloat16 else 'f32', 'data': 'synthetic',
@@ -224,6 +233,10 @@ def main():
                        'parallelism': 'dp%d' % world, 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
         }
         gf = GF_PER_CLIP_FWD_BWD.get(a.frames) if (a.size == 224 and a.depth == 12) else None
+        if gf and a.eval:
+            gf = gf / 3.0                               # forward only (fwd+bwd = 3 x fwd)
+            out['config']['workload'] = out['config']['workload'].replace('train step (fwd+bwd+grad all-reduce+SGD)',
+                                                                            'eval forward (no_grad, BN running stats)')
         if gf:
             out['model_tflops_per_gpu'] = round(value / world * gf / 1e3, 2)
             out['model_mfma_frac'] = round(value / world * gf / 1e3 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS), 4)
@@ -231,7 +244,7 @@ def main():
             out['roofline'] = roof
         if kern:
             out['kernels'] = kern
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.eval:
             out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -228,3 +228,39 @@ def test_side_stream_weight_gradients_match_single_stream():
     for a, b in zip(*results):
         assert float(a.norm()) > 0
         assert relerr(b, a) < 1e-5
+
+
+def test_eval_forward_vs_oracle():
+    """SURVEY 8(f) row 1 (train_CNN.py:837-944): model.eval() + no_grad forward.  BatchNorm uses its running
+    statistics (made non-trivial here by one training forward on both sides), nothing is written back, and the logits
+    match the oracle run with training=False; the same in bfloat16 tracks the float32 logits."""
+    R, p, x, labels, grid = _oracle_case(2, 4, 96, 2)
+    g = torch.Generator().manual_seed(7)
+    x2 = torch.randn(x.shape, generator=g)
+    pr = {k: v.clone() for k, v in p.items()}
+    with torch.no_grad():
+        R.xception_vidtr_forward(pr, x, depth=2, training=True)            # moves the running statistics
+        ref = R.xception_vidtr_forward(pr, x2, depth=2, training=False)
+    model = _hip_model(p, 4, grid, 2)
+    with torch.no_grad():
+        model(x.cuda())                                                     # train mode: running stats updated
+    model.eval()
+    before = {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}
+    with torch.no_grad():
+        out = model(x2.cuda())
+        out_again = model(x2.cuda())
+    assert relerr(out, ref) < 1e-3
+    assert torch.equal(out, out_again)
+    after = model.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items()), 'eval forward must not touch the running statistics'
+    assert relerr(after['xcep.model.bn1.running_var'], pr['xcep.model.bn1.running_var']) < 1e-4
+    # clips are independent in eval mode (no batch statistics): a clip alone gives the logit it gives in the batch
+    with torch.no_grad():
+        solo = model(x2[1:2].cuda())
+    assert relerr(solo, out[1:2]) < 1e-5
+    mb = _hip_model(p, 4, grid, 2, dtype=torch.bfloat16)
+    mb.load_state_dict(model.state_dict())
+    mb.eval()
+    with torch.no_grad():
+        outb = mb(x2.cuda())
+    assert float((outb.float() - out).abs().max()) < 5e-2 * max(1.0, float(out.abs().max()))
