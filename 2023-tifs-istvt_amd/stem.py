@@ -91,9 +91,11 @@ def bn_apply(u: Tensor, st: BNState, M: int, C: int, relu: bool) -> Tensor:
     return y
 
 
-def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: int, stats: Optional[Tensor] = None):
+def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: int, stats: Optional[Tensor] = None,
+                dg: Optional[Tensor] = None, db: Optional[Tensor] = None):
     """-> (du, dgamma, dbeta).  `stats` = new_stats() buffer already accumulated (not yet reduced) by a
-    fused producer (the depthwise input-gradient kernel)."""
+    fused producer (the depthwise input-gradient kernel).  dg / db: float32 [C] buffers to accumulate into
+    (a parameter's .grad); fresh zero tensors otherwise."""
     L = _lib.lib()
     if stats is None:
         stats = new_stats(C, u.device)
@@ -102,8 +104,10 @@ def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: in
                    'istvt_bn_bwd_stats')
     reduce_stats(stats, C)
     du = torch.empty_like(u)
-    dg = torch.zeros((C,), dtype=torch.float32, device=u.device)
-    db = torch.zeros((C,), dtype=torch.float32, device=u.device)
+    if dg is None:
+        dg = torch.zeros((C,), dtype=torch.float32, device=u.device)
+    if db is None:
+        db = torch.zeros((C,), dtype=torch.float32, device=u.device)
     _lib.check(L.istvt_bn_bwd_apply(dz.data_ptr(), u.data_ptr(), st.ptr(), gamma.data_ptr(),
                                     stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), du.data_ptr(), dg.data_ptr(),
                                     db.data_ptr(), M, C, dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
@@ -130,8 +134,10 @@ def dwconv(x: Tensor, w9: Tensor, Fr: int, H: int, W: int, C: int, *, in_bn: Opt
     return out
 
 
-def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn: Optional[BNState], in_relu: bool) -> Tensor:
-    dw = torch.zeros((C, 9), dtype=torch.float32, device=x.device)
+def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn: Optional[BNState], in_relu: bool,
+                 out: Optional[Tensor] = None) -> Tensor:
+    """out: float32 [C][9] buffer to accumulate into (a depthwise weight's .grad viewed (C, 9))."""
+    dw = out if out is not None else torch.zeros((C, 9), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().istvt_dwconv3x3_wgrad(x.data_ptr(), in_bn.ptr() if in_bn else None, int(in_relu), dout.data_ptr(),
                                                 dw.data_ptr(), Fr, H, W, C, dtype_code(x), _stream()),
                'istvt_dwconv3x3_wgrad')
@@ -285,42 +291,71 @@ class StemFn(Function):
         P, Fr, dtype = sv['P'], sv['Fr'], sv['dtype']
         dtc = ops._DT[dtype]
         grads = {}
+
+        # A parameter registered with GradBucket(fuse_accumulate=True) receives its gradient straight in .grad (the
+        # kernels accumulate) and autograd gets None for it: no zero fill, no add pass, no copy per parameter.
+        def tgt(n, shape):
+            q = P[n]
+            if getattr(q, '_istvt_fused_grad', False) and q.grad is not None and q.grad.is_contiguous():
+                grads[n] = None
+                return q.grad.view(shape)
+            return None
+
+        def bn_bwd(dz, u, st, n, M, C, stats=None):
+            tg, tb = tgt(n + '.weight', (C,)), tgt(n + '.bias', (C,))
+            du, dg, db = bn_backward(dz, u, st, P[n + '.weight'], M, C, stats=stats, dg=tg, db=tb)
+            if tg is None:
+                grads[n + '.weight'] = dg
+            if tb is None:
+                grads[n + '.bias'] = db
+            return du
+
+        def lin_wgrad(n, dyv, xv):
+            q = P[n]
+            t = tgt(n, (q.shape[0], -1))
+            r = ops.linear_wgrad(dyv, xv, out=t)
+            if t is None:
+                grads[n] = r
+
+        def dw_wgrad(n, xv, dv, H_, C_, bn_, relu_):
+            t = tgt(n, (C_, 9))
+            r = dwconv_wgrad(xv, dv, Fr, H_, H_, C_, bn_, relu_, out=t)
+            if t is None:
+                grads[n] = r
+
         dOut = _c(dy).reshape(-1, 728)
         for blk in reversed(sv['blocks']):
             name, i0, cin, cout, H, Hs = blk['name'], blk['i0'], blk['cin'], blk['cout'], blk['H'], blk['Hs']
             M, Ms = Fr * H * H, Fr * Hs * Hs
             dev = dOut.device
             # skip path: skipbn -> 1x1 stride-2 conv
-            duS, dg, db = bn_backward(dOut, blk['uS'], blk['bnS'], P[name + '.skipbn.weight'], Ms, cout)
-            grads[name + '.skipbn.weight'], grads[name + '.skipbn.bias'] = dg, db
-            grads[name + '.skip.weight'] = ops.linear_wgrad(duS, blk['xs'])
+            duS = bn_bwd(dOut, blk['uS'], blk['bnS'], name + '.skipbn', Ms, cout)
+            lin_wgrad(name + '.skip.weight', duS, blk['xs'])
             dxs = ops.linear_dgrad(duS, blk['wsk'])
             # rep path: maxpool -> BN_B -> pointwise_B -> depthwise_B -> ReLU -> BN_A -> pointwise_A -> depthwise_A
             dzB = torch.empty((M, cout), dtype=dtype, device=dev)
             _lib.check(L.istvt_pool_bwd(dOut.data_ptr(), blk['amax'].data_ptr(), dzB.data_ptr(), Fr, H, H, cout, dtc,
                                         _stream()), 'istvt_pool_bwd')
             nB = '%s.rep.%d' % (name, i0 + 4)
-            duB, dg, db = bn_backward(dzB, blk['uB'], blk['bnB'], P[nB + '.weight'], M, cout)
-            grads[nB + '.weight'], grads[nB + '.bias'] = dg, db
+            duB = bn_bwd(dzB, blk['uB'], blk['bnB'], nB, M, cout)
             del dzB
             sB = '%s.rep.%d' % (name, i0 + 3)
-            grads[sB + '.pointwise.weight'] = ops.linear_wgrad(duB, blk['d2'])
+            lin_wgrad(sB + '.pointwise.weight', duB, blk['d2'])
             dd2 = ops.linear_dgrad(duB, blk['wpwB'])
             del duB
-            grads[sB + '.conv1.weight'] = dwconv_wgrad(blk['uA'], dd2, Fr, H, H, cout, blk['bnA'], True)
+            dw_wgrad(sB + '.conv1.weight', blk['uA'], dd2, H, cout, blk['bnA'], True)
             statsA = new_stats(cout, dev)
             dzA = dwconv(dd2, blk['wdwB'], Fr, H, H, cout, flip=True, msrc=blk['uA'], m_bn=blk['bnA'], mask_pre=True,
                          stats=statsA)
             del dd2
             nA = '%s.rep.%d' % (name, i0 + 1)
-            duA, dg, db = bn_backward(dzA, blk['uA'], blk['bnA'], P[nA + '.weight'], M, cout, stats=statsA)
-            grads[nA + '.weight'], grads[nA + '.bias'] = dg, db
+            duA = bn_bwd(dzA, blk['uA'], blk['bnA'], nA, M, cout, stats=statsA)
             del dzA
             sA = '%s.rep.%d' % (name, i0)
-            grads[sA + '.pointwise.weight'] = ops.linear_wgrad(duA, blk['d1'])
+            lin_wgrad(sA + '.pointwise.weight', duA, blk['d1'])
             dd1 = ops.linear_dgrad(duA, blk['wpwA'])
             del duA
-            grads[sA + '.conv1.weight'] = dwconv_wgrad(blk['X'], dd1, Fr, H, H, cin, None, blk['pre_relu'])
+            dw_wgrad(sA + '.conv1.weight', blk['X'], dd1, H, cin, None, blk['pre_relu'])
             if blk['pre_relu']:
                 # d(block input) = relu'(X) * d(rep path) + scatter(d skip path)
                 dOut = dwconv(dd1, blk['wdwA'], Fr, H, H, cin, flip=True, msrc=blk['X'], mask_pre=True, addsrc=dxs)
@@ -333,8 +368,7 @@ class StemFn(Function):
         # bn2 -> conv2
         H1, H2, S = sv['H1'], sv['H2'], sv['S']
         M1, M2 = Fr * H1 * H1, Fr * H2 * H2
-        du2, dg, db = bn_backward(dOut, sv['u2'], sv['bn2'], P['bn2.weight'], M2, 64, stats=stats2)
-        grads['bn2.weight'], grads['bn2.bias'] = dg, db
+        du2 = bn_bwd(dOut, sv['u2'], sv['bn2'], 'bn2', M2, 64, stats=stats2)
         dz1 = torch.empty((M1, 32), dtype=dtype, device=du2.device)
         if dtype == torch.bfloat16:
             du2 = du2.contiguous()
@@ -357,8 +391,7 @@ class StemFn(Function):
                        'istvt_col2im3x3')
             del dcol2
         grads['conv2.weight'] = dW2.view(64, 3, 3, 32).permute(0, 3, 1, 2).contiguous()
-        du1, dg, db = bn_backward(dz1, sv['u1'], sv['bn1'], P['bn1.weight'], M1, 32)
-        grads['bn1.weight'], grads['bn1.bias'] = dg, db
+        du1 = bn_bwd(dz1, sv['u1'], sv['bn1'], 'bn1', M1, 32)
         del dz1
         if dtype == torch.bfloat16 and H1 <= 128:
             du1 = du1.contiguous()
@@ -380,7 +413,7 @@ class StemFn(Function):
             dx = torch.empty_like(sv['x'])
             _lib.check(L.istvt_col2im_conv1(dcol1.data_ptr(), dx.data_ptr(), Fr, S, dtc, _stream()), 'istvt_col2im_conv1')
         ctx.sv = None
-        out = [grads[n].view(P[n].shape) for n in param_names()]
+        out = [None if grads[n] is None else grads[n].view(P[n].shape) for n in param_names()]
         return (dx, None, None, None, *out)
 
 
