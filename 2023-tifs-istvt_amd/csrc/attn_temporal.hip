@@ -457,7 +457,10 @@ extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void
     static const int mfma_bwd_min = getenv("ISTVT_TATTN_MFMA_BWD_MINF") ? atoi(getenv("ISTVT_TATTN_MFMA_BWD_MINF")) : 1;
     if (use_mfma && dtype == DT_BF16 && F >= mfma_bwd_min && F <= 32 && (dh == 64 || dh == 32)) {
         const long nprob = (long)B * P * heads;
-        dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
+        long nwg = (nprob + 3) / 4;
+        const long resident = 256L * (F <= 16 ? 4 : 2);      // workgroups per CU by registers (105 / 213 VGPRs at dh 64)
+        if (nwg > resident) nwg = resident;                   // wavefronts loop over problems
+        dim3 grid((unsigned)nwg), block(256);
 #define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale)
         if (dh == 64) { if (F <= 16) TATTN_B(64, 1); else TATTN_B(64, 2); }
         else { if (F <= 16) TATTN_B(32, 1); else TATTN_B(32, 2); }

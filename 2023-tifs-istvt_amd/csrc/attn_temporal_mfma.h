@@ -181,39 +181,70 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * IMG];
     __shared__ __attribute__((aligned(16))) float stat[4][3][16 * NTL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
-    const long prob = (long)blockIdx.x * 4 + wave;
-    if (prob >= (long)B * P * heads) return;
-    const int h = (int)(prob % heads);
-    const long bp = prob / heads, b = bp / P, p = bp % P;
+    const long total = (long)B * P * heads, nwaves = (long)gridDim.x * 4;
+    long prob = (long)blockIdx.x * 4 + wave;
+    if (prob >= total) return;                            // no workgroup-level synchronisation below
     const int inner = heads * DH;
-    const long row0 = b * F * P + p;
     const long sq = (long)P * 2 * inner, sv = (long)P * inner;
-    const bf16_t* qp = qk + row0 * 2 * inner + h * DH;
-    const bf16_t* kp = qp + inner;
-    const bf16_t* vp = v + row0 * inner + h * DH;
-    const bf16_t* dop = dout + row0 * inner + h * DH;
-    bf16_t* dqp = dqk + row0 * 2 * inner + h * DH;
-    bf16_t* dkp = dqp + inner;
-    bf16_t* dvp = dv + row0 * inner + h * DH;
     bf16_t* Qimg = smem[wave];
     bf16_t* Kimg = Qimg + IMG;
     bf16_t* Dimg = Kimg + IMG;
     float (*st)[16 * NTL] = stat[wave];
     const float c = scale * TM_LOG2E;
-
-    tmf::stage32<DH, NTL>(Qimg, qp, sq, F, lane);
-    tmf::stage32<DH, NTL>(Kimg, kp, sq, F, lane);
-    tmf::stage32<DH, NTL>(Dimg, dop, sv, F, lane);
-    // operands used un-transposed, straight from global memory in fragment layout (row 16t + r, columns 32ks + 8g)
+    // A wavefront walks problems prob, prob + nwaves, ...: everything the next problem needs from HBM (the Q, K, dO
+    // rows for the three LDS images and the V fragments) is requested before the current one is computed and waits
+    // in registers -- one problem per wavefront left five wavefronts per SIMD each idling through its own latency.
+    constexpr int VPR = DH / 8, RPI = 64 / VPR, NIT = 16 * NTL / RPI;
+    bf16x8 nq[NIT], nk[NIT], nd[NIT], nv[NTL][KS];
+    auto fetch = [&](long pr) {
+        const int h = (int)(pr % heads);
+        const long bp = pr / heads, b = bp / P, pp = bp % P;
+        const long row0 = b * F * P + pp;
+        const bf16_t* qp = qk + row0 * 2 * inner + h * DH;
+        const bf16_t* kp = qp + inner;
+        const bf16_t* vp = v + row0 * inner + h * DH;
+        const bf16_t* dop = dout + row0 * inner + h * DH;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
+            nq[it] = tmf::row_frag(qp, sq, row, F, col);
+            nk[it] = tmf::row_frag(kp, sq, row, F, col);
+            nd[it] = tmf::row_frag(dop, sv, row, F, col);
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) nv[t][ks] = tmf::row_frag(vp, sv, 16 * t + r, F, 32 * ks + 8 * g);
+    };
+    fetch(prob);
+    for (; prob < total; prob += nwaves) {
+    const int h = (int)(prob % heads);
+    const long bp = prob / heads, b = bp / P, p = bp % P;
+    const long row0 = b * F * P + p;
+    bf16_t* dqp = dqk + row0 * 2 * inner + h * DH;
+    bf16_t* dkp = dqp + inner;
+    bf16_t* dvp = dv + row0 * inner + h * DH;
+    tmf::wave_lds_fence();                                // the previous problem's image reads are done
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
+        *reinterpret_cast<bf16x8*>(Qimg + row * LDI + col) = nq[it];
+        *reinterpret_cast<bf16x8*>(Kimg + row * LDI + col) = nk[it];
+        *reinterpret_cast<bf16x8*>(Dimg + row * LDI + col) = nd[it];
+    }
     bf16x8 kf[NTL][KS], vf[NTL][KS];
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
-            vf[t][ks] = tmf::row_frag(vp, sv, 16 * t + r, F, 32 * ks + 8 * g);
-        }
+        for (int ks = 0; ks < KS; ++ks) vf[t][ks] = nv[t][ks];
     tmf::wave_lds_fence();
+    if (prob + nwaves < total) fetch(prob + nwaves);
+    // K rows in fragment layout (row 16t + r, columns 32ks + 8g), from the image
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            kf[t][ks] = *reinterpret_cast<const bf16x8*>(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
 
     // ---- part 1: per query tile u -- S^T, dP^T (keys on rows, queries on lanes), statistics, dQ
 #pragma unroll
@@ -223,8 +254,8 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         bf16x8 qf[KS], dof[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = tmf::row_frag(qp, sq, q, F, 32 * ks + 8 * g);
-            dof[ks] = tmf::row_frag(dop, sv, q, F, 32 * ks + 8 * g);
+            qf[ks] = *reinterpret_cast<const bf16x8*>(Qimg + q * LDI + 32 * ks + 8 * g);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(Dimg + q * LDI + 32 * ks + 8 * g);
         }
         f32x4 s[2], dp[2];
         s[1] = f32x4{0, 0, 0, 0};
@@ -325,4 +356,5 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
             }
         }
     }
+    }   // problems of this wavefront
 }
