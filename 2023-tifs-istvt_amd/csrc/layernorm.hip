@@ -12,6 +12,7 @@
 // so the forward writes both y and diff in one pass (one wavefront walks the F frames of a
 // position), and the backward folds  dy = g_y + g_diff[f] - g_diff[f+1]  into its load.
 #include "common.h"
+#include <cstdlib>
 
 constexpr int LN_MAXCH = 2;   // chunks of 8 per lane -> D <= 1024
 
@@ -331,7 +332,11 @@ extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, 
     if (dy2 && (F <= 0 || P <= 0 || M % ((long)F * P) != 0)) return ISTVT_ERR_SHAPE;
     if (!dy2) { F = 1; P = 1; }
     long blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    // every workgroup ends with one atomic per column per accumulator into the SAME 728 (x2, x3) addresses; they all
+    // finish together, so the tail grows with the workgroup count: measured at C2 (38 launches / step)
+    // 256 -> 2.95 ms, 512 -> 2.83 ms, 1024 -> 3.28 ms, 2048 -> 3.84 ms
+    static const long cap = getenv("ISTVT_LN_BWD_BLOCKS") ? atol(getenv("ISTVT_LN_BWD_BLOCKS")) : 512;
+    if (blocks > cap) blocks = cap;
     if (dcol)
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, true>), dim3((int)blocks), dim3(256), 0, stream,
                                                  (const T*)dy, (const T*)dy2, (const T*)x, mean, rstd, gamma,
