@@ -94,7 +94,8 @@ __device__ __forceinline__ void colreduce_block(F f, double* const (&out)[NACC],
 
 static void colreduce_grid(long M, int C, dim3& grid, int& rpb) {
     const int gx = (C / 8 + 255) / 256;
-    long target = 2048 / gx;
+    static const long wg_target = getenv("ISTVT_COLRED_BLOCKS") ? atol(getenv("ISTVT_COLRED_BLOCKS")) : 512;   // 2048: +0.6 ms per step (fp64 atomics tail per workgroup); 256: +0.03
+    long target = wg_target / gx;
     if (target < 1) target = 1;
     rpb = (int)((M + target - 1) / target);
     if (rpb < 32) rpb = 32;
@@ -787,7 +788,8 @@ extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
     const int cy = (C + DW_CC - 1) / DW_CC;
-    long bx = 2048 / cy;
+    static const long wg_cap = getenv("ISTVT_DWW_BLOCKS") ? atol(getenv("ISTVT_DWW_BLOCKS")) : 512;   // = resident workgroups; 2048 was 4 % slower (atomics tail per workgroup)
+    long bx = wg_cap / cy;
     if (bx < 1) bx = 1;
     if (bx > tiles) bx = tiles;
     dim3 grid((unsigned)(bx * cy));                        // slot-major, channel chunk fastest
