@@ -1,6 +1,7 @@
 // Small HBM-bound helpers of the transformer path: column sums (bias gradients), token
 // assembly (reference DSTTr.forward, network/vivit/vivit.py:133-142) and dtype casts.
 #include "common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
 // out[n] += sum_m x[m][n]   (bias gradient of a Linear: colsum of dY).  fp32 accumulate, one
@@ -46,7 +47,8 @@ extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, i
     if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0) return ISTVT_ERR_SHAPE;
     // 256 row blocks: every block ends with one float atomic per column into the SAME N addresses, and same-address
     // atomics serialise at the memory side (1024 row blocks were slower than 256 although the loads ran faster)
-    int rpb = (int)((M + 255) / 256);
+    static const long rb = getenv("ISTVT_COLSUM_ROWBLOCKS") ? atol(getenv("ISTVT_COLSUM_ROWBLOCKS")) : 256;
+    int rpb = (int)((M + rb - 1) / rb);
     if (rpb < 64) rpb = 64;
     dim3 grid((N + 511) / 512, (unsigned)((M + rpb - 1) / rpb)), block(256);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)x, out, M, N, ld, rpb));
