@@ -336,7 +336,16 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                     hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
                 cus = n & ~7;
             }
-            const int G = tiles < cus ? tiles : cus;
+            // Balanced rounds: 666 tiles on 256 CUs are three rounds whichever way they are dealt; dealing them to 224
+            // workgroups (3 tiles each) takes the same time and leaves 32 CUs free for the whole launch -- for the
+            // weight-gradient GEMM running on the side stream -- instead of 102 CUs free for the last round only.
+            static const int balance = getenv("ISTVT_GEMM_BALANCE") ? atoi(getenv("ISTVT_GEMM_BALANCE")) : 1;
+            int G = tiles < cus ? tiles : cus;
+            if (balance && tiles > cus) {
+                const int rounds = (tiles + cus - 1) / cus;
+                const int g8 = (((tiles + rounds - 1) / rounds) + 7) & ~7;     // multiple of 8: blockIdx & 7 stays the XCD
+                if (g8 < G) G = g8;
+            }
             static const int qk = getenv("ISTVT_GEMM_Q") ? atoi(getenv("ISTVT_GEMM_Q")) : 1;
 #ifdef ISTVT_GEMM_DIAG
             static const int qdbg = getenv("ISTVT_GEMM_QDBG") ? atoi(getenv("ISTVT_GEMM_QDBG")) : 0;
