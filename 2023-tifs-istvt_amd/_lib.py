@@ -55,6 +55,8 @@ SIGNATURES = {
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
     'istvt_cast_transpose': [P, L, P, L, P, L, I, I, P],
+    'istvt_sgd_momentum': [P, P, P, L, F, F, F, F, I, I, I, P],
+    'istvt_adamw': [P, P, P, P, L, F, F, F, F, F, L, I, P],
 }
 
 _lib = None

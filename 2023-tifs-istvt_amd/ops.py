@@ -83,6 +83,13 @@ def rows(t: Tensor) -> Tuple[Tensor, int]:
 # ------------------------------------------------------------------------------------------
 # fp32 master weight -> compute-dtype operand, cached per parameter version
 _wcache: dict = {}
+_wepoch = [0]          # bumped by writers that modify parameters behind autograd's back (parallel.FusedSGD / FusedAdamW)
+
+
+def invalidate_weight_cache():
+    """A kernel wrote parameters through raw pointers (no ``_version`` bump): drop every cached operand copy."""
+    _wepoch[0] += 1
+
 G256_MIN = 64          # smallest output edge routed to the 256x256 DMA GEMM (mirrors ISTVT_G256_MIN in gemm.hip)
 
 
@@ -110,7 +117,7 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
     pad = pad and w2.shape[1] % 8 == 0 and pad_ld(w2.shape[1]) != w2.shape[1]
     key = (id(w), 'p') if pad else id(w)    # id-keyed: Tensor.__eq__ is elementwise, so tensors cannot be dict keys
     hit = _wcache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].dtype == dtype:
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, _wepoch[0]) and hit[2].dtype == dtype:
         return hit[2]
     if pad:
         w2 = _c(w2)
@@ -128,7 +135,7 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
                                                out.stride(0), R, C, _stream()), 'istvt_cast2d')
     else:
         out = cast(w2, dtype)
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), (w._version, _wepoch[0]), out)
     return out
 
 
@@ -240,12 +247,12 @@ def weight_t_as(w: Tensor, dtype: torch.dtype) -> Tensor:
     optimizer step is noise next to transposing activations."""
     key = (id(w), 't')
     hit = _wcache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].dtype == dtype:
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, _wepoch[0]) and hit[2].dtype == dtype:
         return hit[2]
     wt = weight_as(w, dtype).t()
     out = empty_rows(wt.shape[0], wt.shape[1], dtype, w.device)
     out.copy_(wt)
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), w._version, out)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), (w._version, _wepoch[0]), out)
     return out
 
 

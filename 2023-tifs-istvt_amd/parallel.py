@@ -36,9 +36,12 @@ def live_named_parameters(model: torch.nn.Module) -> List[Tuple[str, torch.nn.Pa
 class GradBucket:
     """Flat fp32 gradient buffer; every live parameter's ``.grad`` is a view into it."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], fuse_accumulate: bool = False):
+    def __init__(self, params: Iterable[torch.nn.Parameter], fuse_accumulate: bool = False,
+                 flatten_params: bool = False):
         """fuse_accumulate: let the HIP weight-gradient kernels add straight into the bucket
-        (functional._target) instead of returning fresh tensors for autograd to add."""
+        (functional._target) instead of returning fresh tensors for autograd to add.
+        flatten_params: also move the parameters themselves into one flat fp32 buffer (``flat_params``; each
+        ``p.data`` becomes a view of it, values preserved) -- what FusedSGD / FusedAdamW step over."""
         self.params = list(params)
         for p in self.params:
             p._istvt_fused_grad = bool(fuse_accumulate)
@@ -52,6 +55,18 @@ class GradBucket:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        self.flat_params = None
+        if flatten_params:
+            if any(p.dtype != torch.float32 for p in self.params):
+                raise TypeError('flatten_params needs float32 parameters')
+            self.flat_params = torch.empty(self.numel, dtype=torch.float32, device=dev)
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                view = self.flat_params[off:off + n].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                off += n
 
     def zero(self):
         self.flat.zero_()
@@ -88,3 +103,71 @@ def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
         raise ValueError('global batch %d is not divisible by world size %d' % (b, world))
     per = b // world
     return x[rank * per:(rank + 1) * per]
+
+
+class _FusedOptimizer:
+    """Common part of the fused optimizers: one HIP launch over GradBucket's flat parameter / gradient buffers
+    (reference optimizers: train_CNN.py:196-201).  ``zero_grad=True`` makes the step kernel
+    write zeros over the gradients it has just consumed, so the training loop needs no zero-grad pass."""
+
+    def __init__(self, bucket: GradBucket, zero_grad: bool):
+        if bucket.flat_params is None:
+            raise ValueError('the fused optimizers need GradBucket(..., flatten_params=True)')
+        if not bucket.flat.is_cuda:
+            raise RuntimeError('the fused optimizers run on the GPU only (no CPU fallback)')
+        self.bucket = bucket
+        self.fused_zero_grad = bool(zero_grad)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        if set_to_none:
+            raise ValueError('gradients are views of the flat bucket: they cannot be set to None')
+        if not (self.fused_zero_grad and self.steps > 0):
+            self.bucket.zero()
+
+    def _done(self):
+        from . import ops
+        self.steps += 1
+        ops.invalidate_weight_cache()       # the kernel wrote parameters without bumping their version counters
+
+
+class FusedSGD(_FusedOptimizer):
+    """torch.optim.SGD(params, lr, momentum, dampening, weight_decay, nesterov) over the flat buffers."""
+
+    def __init__(self, bucket: GradBucket, lr: float, momentum: float = 0.0, dampening: float = 0.0,
+                 weight_decay: float = 0.0, nesterov: bool = False, zero_grad: bool = False):
+        super().__init__(bucket, zero_grad)
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')
+        self.lr, self.momentum, self.dampening = float(lr), float(momentum), float(dampening)
+        self.weight_decay, self.nesterov = float(weight_decay), bool(nesterov)
+        self.momentum_buffer = torch.zeros_like(bucket.flat)
+
+    def step(self):
+        from . import _lib, ops
+        b = self.bucket
+        _lib.check(_lib.lib().istvt_sgd_momentum(b.flat_params.data_ptr(), b.flat.data_ptr(), self.momentum_buffer.data_ptr(),
+                                                 b.numel, self.lr, self.momentum, self.dampening, self.weight_decay,
+                                                 int(self.nesterov), int(self.steps == 0), int(self.fused_zero_grad),
+                                                 ops._stream()), 'istvt_sgd_momentum')
+        self._done()
+
+
+class FusedAdamW(_FusedOptimizer):
+    """torch.optim.AdamW(params, lr, betas, eps, weight_decay) (amsgrad off) over the flat buffers."""
+
+    def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2, zero_grad: bool = False):
+        super().__init__(bucket, zero_grad)
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.exp_avg = torch.zeros_like(bucket.flat)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat)
+
+    def step(self):
+        from . import _lib, ops
+        b = self.bucket
+        _lib.check(_lib.lib().istvt_adamw(b.flat_params.data_ptr(), b.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                          self.exp_avg_sq.data_ptr(), b.numel, self.lr, self.betas[0], self.betas[1],
+                                          self.eps, self.weight_decay, self.steps + 1, int(self.fused_zero_grad),
+                                          ops._stream()), 'istvt_adamw')
+        self._done()

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--eval', action='store_true',
                     help='SURVEY 8(f) row 1: model.eval() + no_grad forward only (train_CNN.py:837-944); a different metric')
+    ap.add_argument('--torch-optimizer', action='store_true',
+                    help='torch.optim.SGD + a separate zero-grad pass instead of the fused HIP optimizer step')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
     return ap.parse_args()
@@ -108,8 +110,11 @@ def main():
                           attn_fp8=a.attn_fp8).to(dev).train()
     parallel.broadcast_parameters(model)
     live = [p for _, p in parallel.live_named_parameters(model)]
-    bucket = parallel.GradBucket(live, fuse_accumulate=True)
-    opt = torch.optim.SGD(live, lr=1e-3, momentum=0.9, weight_decay=0)     # train_CNN.py:200
+    bucket = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=not a.torch_optimizer)
+    if a.torch_optimizer:
+        opt = torch.optim.SGD(live, lr=1e-3, momentum=0.9, weight_decay=0)     # train_CNN.py:200
+    else:                                   # the same update in one launch over the flat buffers, zero-grad included
+        opt = parallel.FusedSGD(bucket, lr=1e-3, momentum=0.9, weight_decay=0, zero_grad=True)
     crit = torch.nn.BCEWithLogitsLoss()                                      # train_CNN.py:148
 
     g = torch.Generator(device='cpu').manual_seed(1 + rank)
@@ -126,7 +131,10 @@ def main():
         if a.eval:
             with torch.no_grad():
                 return model(x).sum()
-        bucket.zero()
+        if a.torch_optimizer:
+            bucket.zero()
+        else:
+            opt.zero_grad()                 # a pass only before the first step: the fused step re-zeroes the gradients
         logits = model(x)
         loss = crit(logits.view(-1), labels)
         loss.backward()

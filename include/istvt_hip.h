@@ -195,6 +195,16 @@ int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtyp
 int istvt_cast_transpose(const float* in, long ldi, void* out, long ldo, void* outT, long ldt, int R, int C,
                          istvt_stream_t stream);
 
+/* ---- fused optimizer steps over flat float buffers (train_CNN.py:196-201: torch.optim.SGD(momentum) / AdamW) ----
+ * p, g, state: n floats each, 16-byte aligned (parallel.GradBucket(flatten_params=True)).  Semantics are torch.optim's:
+ * sgd: g' = g + wd p; buf = first_step ? g' : momentum buf + (1 - dampening) g'; p -= lr (nesterov ? g' + momentum buf : buf)
+ * adamw (amsgrad off): p *= 1 - lr wd; m, v moments; p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * zero_grad != 0 also writes zeros over g (the next step's zero-grad pass). */
+int istvt_sgd_momentum(float* p, float* g, float* buf, long n, float lr, float momentum, float dampening,
+                       float weight_decay, int nesterov, int first_step, int zero_grad, istvt_stream_t stream);
+int istvt_adamw(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, long step, int zero_grad, istvt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,3 +272,68 @@ def test_eval_forward_vs_oracle():
     with torch.no_grad():
         outb = mb(x2.cuda())
     assert float((outb.float() - out).abs().max()) < 5e-2 * max(1.0, float(out.abs().max()))
+
+
+def test_fused_optimizers_match_torch():
+    """SURVEY 8(f) row 2 (train_CNN.py:196-201): one-launch SGD-momentum / AdamW over the flat buffers against
+    torch.optim on the same parameters, three steps, odd sizes (tail path), with and without the fused zero-grad."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    shapes = [(37, 5), (1001,), (64, 3, 3, 3), (7,)]
+    gen = torch.Generator().manual_seed(3)
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    grads = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(3)]
+    cases = [('sgd', dict(lr=1e-3, momentum=0.9)), ('sgd', dict(lr=5e-2, momentum=0.8, weight_decay=1e-2, nesterov=True)),
+             ('sgd', dict(lr=1e-2, momentum=0.5, dampening=0.3)), ('adamw', dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                                                                                 weight_decay=1e-2))]
+    for kind, kw in cases:
+        for fz in (False, True):
+            ref_p = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+            ref = (torch.optim.SGD if kind == 'sgd' else torch.optim.AdamW)(ref_p, **kw)
+            my_p = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+            bucket = parallel.GradBucket(my_p, flatten_params=True)
+            assert all(torch.equal(a, b) for a, b in zip(my_p, ref_p))           # flattening preserved the values
+            mine = (parallel.FusedSGD if kind == 'sgd' else parallel.FusedAdamW)(bucket, zero_grad=fz, **kw)
+            for step in range(3):
+                ref.zero_grad()
+                mine.zero_grad()
+                for p, q, gval in zip(ref_p, my_p, grads[step]):
+                    p.grad = gval.clone().cuda()
+                    q.grad.add_(gval.cuda())          # accumulate into the bucket view, as the kernels do
+                ref.step()
+                mine.step()
+                if fz:
+                    assert float(bucket.flat.abs().max()) == 0.0
+                for p, q in zip(ref_p, my_p):
+                    assert relerr(q, p) < 2e-6, (kind, kw, fz, step)
+
+
+def test_fused_sgd_trains_the_model_like_torch_sgd():
+    """Two training steps of the model with FusedSGD equal two steps with torch.optim.SGD (the second forward has to see
+    the updated weights: the cached bf16 / padded operand copies are invalidated by the fused step)."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    R, p, x, labels, grid = _oracle_case(2, 4, 96, 2)
+    outs = []
+    for fused in (False, True):
+        model = _hip_model(p, 4, grid, 2, dtype=torch.bfloat16)
+        live = [q for _, q in parallel.live_named_parameters(model)]
+        bucket = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=fused)
+        opt = parallel.FusedSGD(bucket, lr=0.05, momentum=0.9, zero_grad=True) if fused else \
+            torch.optim.SGD(live, lr=0.05, momentum=0.9)
+        seq = []
+        for it in range(3):
+            if fused:
+                opt.zero_grad()
+            else:
+                bucket.zero()
+            out = model(x.cuda())
+            torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+            opt.step()
+            seq.append(out.detach().float().clone())
+        outs.append(seq)
+    assert float((outs[0][0] - outs[0][2]).abs().max()) > 1e-4        # the steps did change the logits
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(a.abs().max()))
