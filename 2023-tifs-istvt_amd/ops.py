@@ -41,7 +41,9 @@ def _ptr(t: Optional[Tensor]):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's current stream; torch.cuda.current_stream() builds a Stream object through three
+    # Python layers (10 us x ~1500 launches per step)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 # ------------------------------------------------------------------------------------------
@@ -129,13 +131,13 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
             _lib.check(_lib.lib().istvt_cast_transpose(w2.data_ptr(), C, out.data_ptr(), out.stride(0), wt.data_ptr(),
                                                        wt.stride(0), R, C, _stream()), 'istvt_cast_transpose')
             tkey = (id(out), 'T')
-            _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey: _wcache.pop(k, None)), 0, wt)
+            _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey, c=_wcache: c.pop(k, None)), 0, wt)
         else:
             _lib.check(_lib.lib().istvt_cast2d(w2.data_ptr(), dtype_code(w2), C, out.data_ptr(), _DT[dtype],
                                                out.stride(0), R, C, _stream()), 'istvt_cast2d')
     else:
         out = cast(w2, dtype)
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), (w._version, _wepoch[0]), out)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), (w._version, _wepoch[0]), out)
     return out
 
 
@@ -252,7 +254,7 @@ def weight_t_as(w: Tensor, dtype: torch.dtype) -> Tensor:
     wt = weight_as(w, dtype).t()
     out = empty_rows(wt.shape[0], wt.shape[1], dtype, w.device)
     out.copy_(wt)
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), (w._version, _wepoch[0]), out)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), (w._version, _wepoch[0]), out)
     return out
 
 
@@ -265,7 +267,7 @@ def _transposed_operand(w: Tensor) -> Tensor:
         return hit[2]
     wt = empty_rows(w.shape[1], w.shape[0], w.dtype, w.device)        # line-aligned rows for the DMA-staged GEMM
     wt.copy_(w.t())
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)), 0, wt)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), 0, wt)
     return wt
 
 

@@ -419,14 +419,14 @@ class StemFn(Function):
 
 def stem_forward(x: Tensor, xcep: torch.nn.Module, dtype: torch.dtype) -> Tensor:
     """Run the HIP stem with the parameters/buffers of an ``Xception`` module (network/xception.py)."""
-    named = dict(xcep.named_parameters())
-    bufs = dict(xcep.named_buffers())
-    params = [named[n] for n in param_names()]
+    # look the tensors up by dotted name every call (a load_state_dict / .to() may have replaced them), but without
+    # walking all 12 Xception blocks with named_parameters(): two module-tree walks cost ~1 ms of host time per step
+    params = [xcep.get_parameter(n) for n in param_names()]
     buffers = []
     for n in bn_names():
-        buffers += [bufs[n + '.running_mean'], bufs[n + '.running_var']]
+        buffers += [xcep.get_buffer(n + '.running_mean'), xcep.get_buffer(n + '.running_var')]
     y = StemFn.apply(x, dtype, xcep.training, buffers, *params)
     if xcep.training:
         for n in bn_names():
-            bufs[n + '.num_batches_tracked'] += 1
+            xcep.get_buffer(n + '.num_batches_tracked').add_(1)
     return y

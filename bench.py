@@ -154,6 +154,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0        # host time to enqueue the steps (the GPU is still running)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -248,6 +249,10 @@ def main():
         if gf:
             out['model_tflops_per_gpu'] = round(value / world * gf / 1e3, 2)
             out['model_mfma_frac'] = round(value / world * gf / 1e3 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS), 4)
+        # Python needs this long to enqueue a step's ~1500 launches; while it stays below ms_per_step the GPU is the
+        # bound.  (Replaying the step as one captured HIP graph was tried: hipGraphLaunch of the 1500-node graph costs
+        # the host 35 ms per replay on this ROCm, no better than the eager loop.)
+        out['host_enqueue_ms_per_step'] = round(t_enq / a.steps * 1e3, 3)
         if roof:
             out['roofline'] = roof
         if kern:
