@@ -119,12 +119,12 @@ class FrameDiffFn(Function):
 
 # Weight gradients on a second HIP stream.  Nothing downstream in the backward pass reads a weight gradient, so the
 # TN GEMM + split-K reduce of a Linear are enqueued on a side stream that waits for the main stream at the point of
-# the call (dy and x are complete there) and is joined back into the main stream by an end-of-backward callback.
+# the call (dy and x are complete there) and is joined back into the main stream by an end-of-backward callback, which also releases the operands.
 # The hardware then fills the partial last round of the persistent input-gradient GEMMs, and the CUs the
 # bandwidth-bound kernels leave idle, with weight-gradient workgroups.  Only used when the gradient lands directly
 # in the parameter's .grad (GradBucket(fuse_accumulate=True)): a returned tensor would be consumed by autograd on
 # the main stream.  ISTVT_WGRAD_STREAM=0 (or set_wgrad_overlap(False)) serialises everything on one stream.
-_overlap = {'on': os.environ.get('ISTVT_WGRAD_STREAM', '1') != '0', 'streams': {}, 'pending': {}}
+_overlap = {'on': os.environ.get('ISTVT_WGRAD_STREAM', '1') != '0', 'streams': {}, 'pending': {}, 'keep': {}}
 
 
 def set_wgrad_overlap(on: bool):
@@ -135,6 +135,11 @@ def _join_side(dev):
     main = _overlap['pending'].pop(dev, None)
     if main is not None:
         main.wait_stream(_overlap['streams'][dev])
+    # The operands of the side-stream launches were kept alive until here instead of being handed to the allocator with
+    # record_stream(): blocks parked behind side-stream events made the caching allocator grow by a run-dependent
+    # 16-56 GB at C2 (reserved 47-87 GB against 31 GB single-stream).  Released after the join they go back to the main
+    # stream's pool in order: ~10 GB more at the peak, the same every run.
+    _overlap['keep'].pop(dev, None)
 
 
 def _wgrad(dy, x, weight):
@@ -154,8 +159,7 @@ def _wgrad(dy, x, weight):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         ops.linear_wgrad(dy, x, out=out)
-    dy.record_stream(side)      # the caching allocator must not hand these blocks out again before the side
-    x.record_stream(side)       # stream has read them
+    _overlap['keep'].setdefault(dev, []).append((dy, x))     # alive until the join (see _join_side)
     return None
 
 
@@ -169,7 +173,7 @@ def _bgrad(dy, bias):
         side.wait_stream(torch.cuda.current_stream(dy.device))
         with torch.cuda.stream(side):
             ops.colsum(dy, out=buf)
-        dy.record_stream(side)
+        _overlap['keep'].setdefault(dy.device.index, []).append((dy,))
         return None
     ops.colsum(dy, out=buf)
     return ret

@@ -152,9 +152,13 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(a.steps):
         loss = step()
-    t_enq = time.perf_counter() - t0        # host time to enqueue the steps (the GPU is still running)
+        marks.append(time.perf_counter())
+    # host time to enqueue one step, taken from the first two steps after the sync: later ones include waiting for
+    # room in the launch queue (the GPU is ~2.5 steps behind by then)
+    t_enq = (marks[min(1, len(marks) - 1)] - t0) / min(2, len(marks))
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -252,7 +256,11 @@ def main():
         # Python needs this long to enqueue a step's ~1500 launches; while it stays below ms_per_step the GPU is the
         # bound.  (Replaying the step as one captured HIP graph was tried: hipGraphLaunch of the 1500-node graph costs
         # the host 35 ms per replay on this ROCm, no better than the eager loop.)
-        out['host_enqueue_ms_per_step'] = round(t_enq / a.steps * 1e3, 3)
+        out['host_enqueue_ms_per_step'] = round(t_enq * 1e3, 3)
+        ms = torch.cuda.memory_stats(dev)
+        out['allocator'] = {'reserved_GB': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),
+                            'device_allocs': ms.get('num_device_alloc', 0), 'device_frees': ms.get('num_device_free', 0),
+                            'alloc_retries': ms.get('num_alloc_retries', 0)}
         if roof:
             out['roofline'] = roof
         if kern:
