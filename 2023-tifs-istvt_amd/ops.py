@@ -298,11 +298,14 @@ def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Opt
     return dx
 
 
+_WG_TARGET = int(os.environ.get('ISTVT_WGRAD_WGS', '256'))      # workgroups a weight-gradient launch aims for
+
+
 def _pick_splitk(out_rows: int, out_cols: int, red: int, big_tiles: bool = False) -> int:
     """split of the reduction dim for weight gradients so the grid fills the 256 CUs."""
     if big_tiles:          # 256x256 kernel, one workgroup per CU
         tiles = ((out_rows + 255) // 256) * ((out_cols + 255) // 256)
-        s = max(1, 256 // tiles)
+        s = max(1, _WG_TARGET // tiles)
     else:
         tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
         s = max(1, 1024 // tiles)
