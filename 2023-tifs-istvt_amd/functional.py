@@ -131,6 +131,21 @@ def set_wgrad_overlap(on: bool):
     _overlap['on'] = bool(on)
 
 
+def join_side_stream(dev=None):
+    """Make the current backward's main stream wait for the side stream now (instead of at the end of backward): what a
+    caller needs before it hands weight gradients to a collective mid-backward."""
+    if dev is None:
+        dev = torch.cuda.current_device()
+    _join_side(dev)
+
+
+# Callables run by TokensFn.backward once its own kernels are enqueued.  Token assembly is the first operation of the
+# transformer, so at that point every gradient of the transformer (98.8 % of the bucket) has been enqueued -- on the main
+# stream or the side stream -- while the whole stem backward is still to come: parallel.GradBucket hangs the
+# all-reduce of that part of the bucket here to overlap it with the stem backward.
+grad_ready_hooks = []
+
+
 def _join_side(dev):
     main = _overlap['pending'].pop(dev, None)
     if main is not None:
@@ -282,6 +297,8 @@ class TokensFn(Function):
         B, T, hw, D = ctx.geom
         (ds, rs), (dt, rt), (dp, rp) = _target(space), _target(temporal), _target(pos)
         dfeats = ops.tokens_bwd(dx, B, T, hw, D, ds, dt, dp, ctx.needs_input_grad[0])
+        for hook in list(grad_ready_hooks):
+            hook(dx.device)
         return dfeats, rs, rt, rp
 
 

@@ -71,12 +71,52 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def enable_early_all_reduce(self, first_param: int, group=None):
+        """Overlap the gradient all-reduce with the stem backward: the gradients of ``params[first_param:]`` (the
+        transformer, when the parameters are in model order: stem first) are complete when the backward pass reaches
+        the token assembly, long before the stem's are.  Their slice of the bucket is then all-reduced asynchronously
+        (functional.grad_ready_hooks); ``all_reduce()`` later waits for it and reduces the rest.  Needs every gradient
+        of the slice to be written by the kernels themselves (fuse_accumulate=True): a gradient handed back to autograd
+        could still be accumulated after the hook.  No effect without an initialised process group of size > 1."""
+        from . import functional as Fn
+        if not all(getattr(p, '_istvt_fused_grad', False) for p in self.params[first_param:]):
+            raise ValueError('enable_early_all_reduce needs GradBucket(..., fuse_accumulate=True)')
+        lo = sum(p.numel() for p in self.params[:first_param])
+        self._early = (lo, self.numel, group)
+        self._early_work = None
+
+        def on_ready(device):
+            if self._early_work is not None or not (dist.is_available() and dist.is_initialized()):
+                return
+            if dist.get_world_size(group) == 1 or device != self.flat.device:
+                return
+            Fn.join_side_stream(device.index)           # the side-stream weight gradients are part of the slice
+            self._early_work = dist.all_reduce(self.flat[lo:self.numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+        self._on_ready = on_ready
+        Fn.grad_ready_hooks.append(on_ready)
+
+    def disable_early_all_reduce(self):
+        from . import functional as Fn
+        if getattr(self, '_on_ready', None) in Fn.grad_ready_hooks:
+            Fn.grad_ready_hooks.remove(self._on_ready)
+        self._early = None
+
     def all_reduce(self, group=None, chunks: int = 1):
         """sum over ranks then divide by world size (== DataParallel's global-batch mean)."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
         if world == 1:
+            return
+        work = getattr(self, '_early_work', None)
+        if work is not None:                # the transformer's slice is already in flight (enable_early_all_reduce)
+            lo = self._early[0]
+            self._early_work = None
+            if lo > 0:
+                dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM, group=group)
+            work.wait()
+            self.flat.mul_(1.0 / world)
             return
         if chunks <= 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--eval', action='store_true',
                     help='SURVEY 8(f) row 1: model.eval() + no_grad forward only (train_CNN.py:837-944); a different metric')
+    ap.add_argument('--no-early-allreduce', action='store_true',
+                    help='N > 1: one blocking all-reduce after backward instead of starting the transformer slice early')
     ap.add_argument('--torch-optimizer', action='store_true',
                     help='torch.optim.SGD + a separate zero-grad pass instead of the fused HIP optimizer step')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
@@ -88,8 +90,15 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        if os.environ.get('ISTVT_BENCH_REHEARSAL'):
+            # functional rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo instead of RCCL
+            # (the timing of such a run means nothing)
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', rank=rank, world_size=world)
     elif a.gpus > 1:
         raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus)
     else:
@@ -109,13 +118,17 @@ def main():
     model = XceptionVidTr(num_frames=a.frames, grid=grid, depth=a.depth, compute_dtype=dtype,
                           attn_fp8=a.attn_fp8).to(dev).train()
     parallel.broadcast_parameters(model)
-    live = [p for _, p in parallel.live_named_parameters(model)]
+    live_named = parallel.live_named_parameters(model)
+    live = [p for _, p in live_named]
     bucket = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=not a.torch_optimizer)
     if a.torch_optimizer:
         opt = torch.optim.SGD(live, lr=1e-3, momentum=0.9, weight_decay=0)     # train_CNN.py:200
     else:                                   # the same update in one launch over the flat buffers, zero-grad included
         opt = parallel.FusedSGD(bucket, lr=1e-3, momentum=0.9, weight_decay=0, zero_grad=True)
     crit = torch.nn.BCEWithLogitsLoss()                                      # train_CNN.py:148
+    if world > 1 and not a.no_early_allreduce:
+        # the transformer's 98.8 % of the bucket is all-reduced while the stem backward still runs (parallel.py)
+        bucket.enable_early_all_reduce(next(i for i, (n, _) in enumerate(live_named) if n.startswith('vit.')))
 
     g = torch.Generator(device='cpu').manual_seed(1 + rank)
     x = torch.randn((a.batch, a.frames, 3, a.size, a.size), generator=g).to(dev)
@@ -174,6 +187,7 @@ def main():
         ops.gemm_profile = []
         ops.kernel_profile = []
         Fn.set_wgrad_overlap(False)         # one stream: a kernel's duration is then its own, not its neighbour's
+        bucket.disable_early_all_reduce()   # rank 0 alone: nothing collective may start in this step
         step(reduce=False)                  # rank 0 alone: no collective in this extra step
         torch.cuda.synchronize(dev)
         recs, ops.gemm_profile = ops.gemm_profile, None
@@ -243,7 +257,7 @@ def main():
             'config': {'workload': 'C2: B=%d/GPU T=%d %dx%d full ISTVT (Xception stem + %d-layer DSTTr) train step '
                                    '(fwd+bwd+grad all-reduce+SGD), random-init weights' % (a.batch, a.frames, a.size, a.size, a.depth),
                        'global_batch': world * a.batch, 'frames': a.frames, 'size': a.size, 'depth': a.depth,
-                       'parallelism': 'dp%d' % world, 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
+                       'parallelism': 'dp%d' % world, 'early_allreduce': bool(world > 1 and not a.no_early_allreduce), 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
         }
         gf = GF_PER_CLIP_FWD_BWD.get(a.frames) if (a.size == 224 and a.depth == 12) else None
         if gf and a.eval:

@@ -337,3 +337,19 @@ def test_fused_sgd_trains_the_model_like_torch_sgd():
     assert float((outs[0][0] - outs[0][2]).abs().max()) > 1e-4        # the steps did change the logits
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(a.abs().max()))
+
+
+def test_early_all_reduce_two_ranks():
+    """Two ranks (gloo, both on cuda:0): the all-reduce of the transformer's slice started from the token-assembly
+    backward (overlapping the stem backward) gives the gradients of the plain post-backward all-reduce, which equal the
+    mean of the ranks' local gradients."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ddp_worker_gpu.py')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533', worker],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count('early all-reduce used=True') == 2
