@@ -8,9 +8,12 @@
 Workload (BASELINE.json configs[1], "C2"): per GPU B=32 clips x T=8 frames x 3x224x224, full
 ISTVT (Xception stem + 12-layer decomposed spatial-temporal transformer), bf16 activation
 storage / fp32 accumulate, one full training step = zero grads -> forward -> BCE loss ->
-backward -> (N>1: one RCCL all-reduce of the flat gradient bucket) -> SGD-momentum step, on
-synthetic data with random-init weights, inputs resident in HBM.  Weak scaling: the per-GPU batch
-is fixed, so `value` = N * B * K / max-over-ranks(time).
+backward -> (N>1: RCCL all-reduce of the flat gradient bucket, the transformer's slice started
+during the stem backward) -> SGD-momentum step (one fused launch that also re-zeroes the
+gradients), on synthetic data with random-init weights, inputs resident in HBM.  Weak scaling:
+the per-GPU batch is fixed, so `value` = N * B * K / max-over-ranks(time).
+Other modes: --frames 16 (C4), --batch 64 --attn-fp8 (C5), --eval (forward only, a different
+metric), --torch-optimizer, --no-wgrad-overlap, --no-early-allreduce (the plain variants).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the MFMA GEMM: 97 % of
 the model's FLOPs): algorithmic FLOPs of its launches / their duration measured with events on
