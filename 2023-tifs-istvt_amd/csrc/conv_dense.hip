@@ -153,53 +153,89 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_kernel(const bf16_t* __res
         for (int j = 0; j < 8; ++j) wt[(k8 + j) * 64 + co] = v[j];
     }
     __syncthreads();
-    // all 36 row-operand fragments in registers; one wave per 16-pixel group.  The loads are what bounds this kernel:
-    // a du2 pixel is one 128-byte line, so each of the 18 fragment loads of a group touches 16 lines.
+    // all 36 row-operand fragments in registers.  The loads are what bounds this kernel: a du2 pixel is one 128-byte
+    // line, so every fragment load of 16 pixels touches 16 lines.
+    // taps of dy = 1, 2 (24 fragments) stay in registers; the 12 of dy = 0 are read from the LDS image at each use
+    // (register budget: 144 weight + 72 ring registers spilled)
     bf16x8 wf[9][2][2];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 3; tap < 9; ++tap)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 wf[tap][ks][nt] = ld_frag(wt + (tap * 32 + 8 * (r >> 2) + 4 * nt + (r & 3)) * 64 + 32 * ks + 8 * g);
-    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
-        const long m = (long)grp * 16 + r;
-        const bool ok = m < Mi;
-        const long mm = ok ? m : Mi - 1;
-        const int xi = (int)(mm % W);
-        const long t = mm / W;
-        const int yi = (int)(t % H);
-        const long f = t / H;
-        const bf16x8 uraw = ld_frag(u1 + mm * 32 + 8 * g);
-        bf16x8 raw[9][2];
+    const int wrow = 8 * (r >> 2) + (r & 3), wcol = 8 * g;
+    // Work item = (frame, 16-pixel strip, 9 input rows).  Input row y needs the output-gradient rows y, y-1, y-2; walking
+    // down the rows only row y is new (6 fragment loads = 96 lines per 16 pixels instead of 18 loads = 288 lines): the
+    // three rows live in a register ring whose slot is the row index mod 3 -- compile-time, the row loop is unrolled by
+    // three and segments start at multiples of three.
+    constexpr int RSEG = 9;
+    const int nstrips = (W + 15) / 16, nsegs = (H + RSEG - 1) / RSEG;
+    const long nitems = (long)(Mi / ((long)H * W)) * nstrips * nsegs;
+    bf16x8 ring[3][3][2];                               // [row mod 3][dx][ks]
+    for (long it = (long)blockIdx.x * 4 + wave; it < nitems; it += (long)gridDim.x * 4) {
+        const int seg = (int)(it % nsegs);
+        const int strip = (int)((it / nsegs) % nstrips);
+        const long f = it / ((long)nsegs * nstrips);
+        const int xi = strip * 16 + r;
+        const int y0 = seg * RSEG;
+        auto load_row = [&](int yo, bf16x8 (&dst)[3][2]) {
+            const bool rowok = yo >= 0 && yo < Ho;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yo = yi - tap / 3, xo = xi - tap % 3;
-            const bool in = ok && yo >= 0 && yo < Ho && xo >= 0 && xo < Wo;
-            const bf16_t* s = du2 + ((f * Ho + yo) * Wo + xo) * 64 + 8 * g;
-            raw[tap][0] = in ? ld_frag(s) : zero_frag();
-            raw[tap][1] = in ? ld_frag(s + 32) : zero_frag();
-        }
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[nt] = mma16(wf[tap][ks][nt], raw[tap][ks], acc[nt]);
-        if (ok) {                                       // lane (r, g): channels 8g + 4nt + i of pixel r
-            float mu[8], sc[8], be[8];                  // re-read per group (L1): no registers held across the MFMAs
-            load8(bnp + 8 * g, mu);
-            load8(bnp + 2 * 32 + 8 * g, sc);
-            load8(bnp + 3 * 32 + 8 * g, be);
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float z = ((float)uraw[j] - mu[j]) * sc[j] + be[j];
-                o[j] = (bf16_t)(z > 0.f ? acc[j >> 2][j & 3] : 0.f);
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xo = xi - dx;
+                const bool in = rowok && xo >= 0 && xo < Wo;
+                const bf16_t* sp = du2 + ((f * Ho + yo) * Wo + xo) * 64 + 8 * g;
+                dst[dx][0] = in ? ld_frag(sp) : zero_frag();
+                dst[dx][1] = in ? ld_frag(sp + 32) : zero_frag();
             }
-            *reinterpret_cast<bf16x8*>(dz1 + m * 32 + 8 * g) = o;
+        };
+        load_row(y0 - 2, ring[(RSEG * 3 - 2) % 3]);     // y0 is a multiple of 3: rows y0-2, y0-1 sit in slots 1, 2
+        load_row(y0 - 1, ring[(RSEG * 3 - 1) % 3]);
+#pragma unroll
+        for (int k = 0; k < RSEG; ++k) {
+            const int yi = y0 + k;
+            if (yi < H) {                               // uniform (a break would keep the loop from unrolling)
+            load_row(yi, ring[k % 3]);
+            const bool ok = xi < W;
+            const long m = (f * H + yi) * W + (ok ? xi : W - 1);
+            const bf16x8 uraw = ld_frag(u1 + m * 32 + 8 * g);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // the two older rows first: their fragments are already in registers while row yi's loads are in flight
+#pragma unroll
+            for (int dyo = 2; dyo >= 1; --dyo) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[nt] = mma16(wf[dyo * 3 + dx][ks][nt], ring[(k + 3 - dyo) % 3][dx][ks], acc[nt]);
+            }
+            int wo = wrow;
+            asm volatile("" : "+v"(wo));                // keeps the LDS fragment reads inside the loop
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[nt] = mma16(ld_frag(wt + (dx * 32 + wo + 4 * nt) * 64 + 32 * ks + wcol), ring[k % 3][dx][ks], acc[nt]);
+            if (ok) {                                   // lane (r, g): channels 8g + 4nt + i of pixel r
+                float mu[8], sc[8], be[8];              // re-read per row (L1): no registers held across the MFMAs
+                load8(bnp + 8 * g, mu);
+                load8(bnp + 2 * 32 + 8 * g, sc);
+                load8(bnp + 3 * 32 + 8 * g, be);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = ((float)uraw[j] - mu[j]) * sc[j] + be[j];
+                    o[j] = (bf16_t)(z > 0.f ? acc[j >> 2][j & 3] : 0.f);
+                }
+                *reinterpret_cast<bf16x8*>(dz1 + m * 32 + 8 * g) = o;
+            }
+            }
         }
     }
 }
@@ -426,7 +462,8 @@ extern "C" int istvt_conv2_dgrad(const void* du2, const void* w, const void* u1,
     const long Mi = (long)Fr * H * W;
     if (Mi / 16 + 1 > 0x7fffffffL) return ISTVT_ERR_SHAPE;
     const int ngroups = (int)((Mi + 15) / 16);
-    hipLaunchKernelGGL(conv2_dgrad_kernel, dim3(wave_grid(ngroups, 2)), dim3(256), 0, stream, (const bf16_t*)du2,
+    const long items = (long)Fr * ((W + 15) / 16) * ((H + 8) / 9);
+    hipLaunchKernelGGL(conv2_dgrad_kernel, dim3(wave_grid((int)(items < 0x7fffffffL ? items : 0x7fffffffL), 2)), dim3(256), 0, stream, (const bf16_t*)du2,
                        (const bf16_t*)w, (const bf16_t*)u1, bnp, (bf16_t*)dz1, Mi, H, W, H - 2, W - 2, ngroups);
     return istvt_check_launch();
 }
