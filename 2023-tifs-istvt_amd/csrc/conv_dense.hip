@@ -85,53 +85,65 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const bf16_t* __restr
     load8(bnp + 8 * g, mu);
     load8(bnp + 2 * 32 + 8 * g, sc);
     load8(bnp + 3 * 32 + 8 * g, be);
-    const int gstride = gridDim.x * 4;
-    auto fetch = [&](int grp, bf16x8 (&raw)[9]) {
-        const long m = (long)grp * 16 + r;
-        const long mm = m < Mo ? m : Mo - 1;
-        const int xo = (int)(mm % Wo);
-        const long t = mm / Wo;
-        const int yo = (int)(t % Ho);
-        const long f = t / Ho;
-        const bf16_t* src = u1 + ((f * H + yo) * W + xo) * 32 + 8 * g;
+    // Work item = (frame, 16-pixel strip, 9 output rows).  Output row y reads input rows y, y+1, y+2; walking down the
+    // rows only row y+2 is new: it is loaded and put through bn1 + ReLU ONCE (3 fragments instead of 9 per 16 pixels)
+    // into a three-row register ring (slot = input row mod 3: the row loop is unrolled, segments start at multiples of 3).
+    constexpr int RSEG = 9;
+    const int nstrips = (Wo + 15) / 16, nsegs = (Ho + RSEG - 1) / RSEG;
+    const long nitems = (long)(Mo / ((long)Ho * Wo)) * nstrips * nsegs;
+    bf16x8 ring[3][3];                                  // [input row mod 3][dx], already normalised + rectified
+    for (long it = (long)blockIdx.x * 4 + wave; it < nitems; it += (long)gridDim.x * 4) {
+        const int seg = (int)(it % nsegs);
+        const int strip = (int)((it / nsegs) % nstrips);
+        const long f = it / ((long)nsegs * nstrips);
+        const int xo = strip * 16 + r;
+        const bool ok = xo < Wo;
+        const int xc = ok ? xo : Wo - 1;                // lanes past the row end re-read its last pixel, never store
+        const int y0 = seg * RSEG;
+        auto load_row = [&](int yi, bf16x8 (&dst)[3]) {
+            const int yc = yi < H ? yi : H - 1;         // rows past the image only feed output rows that are skipped
+            const bf16_t* sp = u1 + ((f * H + yc) * W + xc) * 32 + 8 * g;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) raw[tap] = ld_frag(src + ((tap / 3) * W + (tap % 3)) * 32);
-    };
-    int grp = blockIdx.x * 4 + wave;
-    bf16x8 cur[9], nxt[9];
-    if (grp < ngroups) fetch(grp, cur);
-    for (; grp < ngroups; grp += gstride) {
-        const bool more = grp + gstride < ngroups;
-        if (more) fetch(grp + gstride, nxt);            // in flight under this group's conversions and MFMAs
-        f32x4 acc[4];
+            for (int dx = 0; dx < 3; ++dx) {
+                const bf16x8 raw = ld_frag(sp + dx * 32);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int lo = lane;
-        asm volatile("" : "+v"(lo));                    // keeps the LDS fragment reads inside the loop
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            bf16x8 xf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xf[j] = (bf16_t)fmaxf(((float)cur[tap][j] - mu[j]) * sc[j] + be[j], 0.f);
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) acc[nt] = mma16(wf[tap][nt], xf, acc[nt]);
-            acc[3] = mma16(wl3[tap * 64 + lo], xf, acc[3]);
-        }
-        const long m = (long)grp * 16 + r;
-        if (m < Mo) {
-            bf16x8 o0, o1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o0[i] = (bf16_t)acc[0][i]; o0[4 + i] = (bf16_t)acc[1][i];
-                o1[i] = (bf16_t)acc[2][i]; o1[4 + i] = (bf16_t)acc[3][i];
+                for (int j = 0; j < 8; ++j)
+                    dst[dx][j] = (bf16_t)fmaxf(((float)raw[j] - mu[j]) * sc[j] + be[j], 0.f);
             }
-            bf16_t* dst = u2 + m * 64 + 16 * g;
-            *reinterpret_cast<bf16x8*>(dst) = o0;
-            *reinterpret_cast<bf16x8*>(dst + 8) = o1;
-        }
-        if (more) {
+        };
+        load_row(y0, ring[0]);
+        load_row(y0 + 1, ring[1]);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) cur[tap] = nxt[tap];
+        for (int k = 0; k < RSEG; ++k) {
+            const int yo = y0 + k;
+            if (yo < Ho) {                              // uniform (a break would keep the loop from unrolling)
+                load_row(yo + 2, ring[(k + 2) % 3]);
+                f32x4 acc[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int lo = lane;
+                asm volatile("" : "+v"(lo));            // keeps the LDS fragment reads inside the loop
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)          // rows y, y+1 are in registers while row y+2 arrives
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const bf16x8& xf = ring[(k + dy) % 3][dx];
+#pragma unroll
+                        for (int nt = 0; nt < 3; ++nt) acc[nt] = mma16(wf[dy * 3 + dx][nt], xf, acc[nt]);
+                        acc[3] = mma16(wl3[(dy * 3 + dx) * 64 + lo], xf, acc[3]);
+                    }
+                if (ok) {
+                    bf16x8 o0, o1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o0[i] = (bf16_t)acc[0][i]; o0[4 + i] = (bf16_t)acc[1][i];
+                        o1[i] = (bf16_t)acc[2][i]; o1[4 + i] = (bf16_t)acc[3][i];
+                    }
+                    bf16_t* dst = u2 + (((f * Ho + yo) * Wo) + xo) * 64 + 16 * g;
+                    *reinterpret_cast<bf16x8*>(dst) = o0;
+                    *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+                }
+            }
         }
     }
 }
@@ -450,7 +462,8 @@ extern "C" int istvt_conv2_fwd(const void* u1, const float* bnp, const void* w, 
     const long Mo = (long)Fr * Ho * Wo;
     if (Mo / 16 + 1 > 0x7fffffffL) return ISTVT_ERR_SHAPE;
     const int ngroups = (int)((Mo + 15) / 16);
-    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(wave_grid(ngroups, 2)), dim3(256), 0, stream, (const bf16_t*)u1, bnp,
+    const long items = (long)Fr * ((Wo + 15) / 16) * ((Ho + 8) / 9);
+    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(wave_grid((int)(items < 0x7fffffffL ? items : 0x7fffffffL), 2)), dim3(256), 0, stream, (const bf16_t*)u1, bnp,
                        (const bf16_t*)w, (bf16_t*)u2, Mo, H, W, Ho, Wo, ngroups);
     return istvt_check_launch();
 }
