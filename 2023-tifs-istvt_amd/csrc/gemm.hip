@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const long stride = (long)gridDim.x * 256 * 4;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
         float4 acc = *reinterpret_cast<const float4*>(out + i);
-        for (int z = 0; z < splits; ++z) {
+#pragma unroll 8
+        for (int z = 0; z < splits; ++z) {       // eight slabs' loads in flight per thread (1.55 -> 1.13 ms per step; 16: same)
             const float4 v = *reinterpret_cast<const float4*>(ws + (long)z * n + i);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
