@@ -368,6 +368,28 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             }
 #endif
             if (qk && q_ok) {       // 64-deep K tiles in 128-byte-row units, two wave groups in ping-pong (gemm256q.h)
+                // 224-row tiles (gemm256q.h) fill the rounds better at the model's shapes (cost = rounds x tile height),
+                // but a tile's time does not shrink with its row count -- the load slot, not the MFMA count, sets the K
+                // loop, and the epilogue is per tile: measured at C2, 254 x 3 tiles of 224 rows against 222 x 3 of 256:
+                // N=728/K=2912 +2 %, N=512/K=728 +2.5 %, the GELU epilogue GEMMs -5..-8 %, the step +0.5 ms.  Off by
+                // default: ISTVT_GEMM_TM=224 forces it, =-1 picks by rounds x height.
+                static const int tm_env = getenv("ISTVT_GEMM_TM") ? atoi(getenv("ISTVT_GEMM_TM")) : 0;
+                const int tiles224 = ((M + 223) / 224) * ((N + T256 - 1) / T256);
+                const long cost256 = (long)((tiles + cus - 1) / cus) * 256, cost224 = (long)((tiles224 + cus - 1) / cus) * 224;
+                const bool use224 = tm_env == 224 || (tm_env == -1 && cost224 < cost256);
+                if (use224) {
+                    int G2 = tiles224 < cus ? tiles224 : cus;
+                    if (balance && tiles224 > cus) {
+                        const int rounds = (tiles224 + cus - 1) / cus;
+                        const int g8 = (((tiles224 + rounds - 1) / rounds) + 7) & ~7;
+                        if (g8 < G2) G2 = g8;
+                    }
+                    if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false, 0, 224>), dim3(G2), block, 0, stream, a);
+                    else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 224>), dim3(G2), block, 0, stream, a);
+                    else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true, 0, 224>), dim3(G2), block, 0, stream, a);
+                    else hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 224>), dim3(G2), block, 0, stream, a);
+                    return istvt_check_launch();
+                }
                 if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
                 else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
                 else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), dim3(G), block, 0, stream, a);

@@ -67,8 +67,15 @@ __device__ __forceinline__ void slot_barrier() {
 // smaller than 2 GiB (32-bit buffer offsets).
 // DBG (diagnostic builds only, -DISTVT_GEMM_DIAG + ISTVT_GEMM_QDBG=n): 1 = no DMA inside the K loop, 2 = no MFMA,
 // 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2.
-template <int EPI, bool SIDE, int DBG = 0>
+// TM = rows of a C tile: 256, or 224 = AL unit (128 rows) + 96 rows of the AH unit (its last four DMA pieces are sent
+// out of range: no traffic, zeros in LDS, same instruction and vmcnt counts), phase B then runs 3 instead of 4 row tiles
+// (24 MFMA).  At M = 56 736 this turns 222 row tiles into 254: an N = 728 GEMM is 762 tiles = 2.98 rounds of 256 CUs of
+// tiles that are 12.5 % shorter, instead of 666 = 2.6 rounds that cost 3.  The host picks per launch (gemm.hip).
+template <int EPI, bool SIDE, int DBG = 0, int TM = 256>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
+    static_assert(TM == 256 || TM == 224, "row tile");
+    constexpr int NB = (TM - 128) / 32;         // 16-row tiles of the AH unit per wavefront: 4 or 3
+    constexpr int HI_HALF = (TM - 128) / 2;     // AH rows per wm half: 64 or 48
     __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
     constexpr bool HAS_SIDE = SIDE || EPI == EPI_GELU_BWD;
     constexpr bool LATE_Q3 = EPI == EPI_GELU_BWD;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int lda = (int)p.lda, ldb = (int)p.ldb, ldc = (int)p.ldc;
 
-    const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + T256 - 1) / T256;
+    const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + TM - 1) / TM;
     const int nwg = tiles_n * tiles_m;
     const int G = gridDim.x;
     const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         const int per_group = gm * tiles_n;
         const int grp = id / per_group, idl = id % per_group;
         const int rows_here = min(gm, tiles_m - grp * gm);
-        bm0 = (grp * gm + idl % rows_here) * T256;
+        bm0 = (grp * gm + idl % rows_here) * TM;
         bn0 = (idl / rows_here) * T256;
     };
 
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const int hr0 = wave * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((hr0 >> 1) & 7);
     unsigned va[2], vb[2];
+    const unsigned ah_dead = (TM == 224 && wave >= 4) ? 0x80000000u : 0u;    // AH rows 96..127 do not exist in a 224-row tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         va[i] = (unsigned)((hr0 + 64 * i) * lda * 2 + chunk * 16);
@@ -147,7 +155,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + i * 8192), 16, vb[i] | deadbit, sb, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, va[i] | deadbit, sa, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16,
+                                                         va[i] | deadbit | (i == 1 ? ah_dead : 0u), sa, 0, 0);
         }
         P += 2;
         if (J0 == 2 && ++p_s == nkt) {
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     // fragment address inside a unit: row (.. + r) * 128 + ((kh*4 + g) ^ ((r >> 1) & 7)) * 16; kh = 1 flips bit 6
     const unsigned la0 = (unsigned)(r * 128 + ((g ^ ((r >> 1) & 7)) << 4));
     const unsigned la_a[2] = {la0 + wm * 64 * 128, (la0 ^ 64u) + wm * 64 * 128};          // + unit base + t * 2048
+    const unsigned la_h[2] = {la0 + wm * HI_HALF * 128, (la0 ^ 64u) + wm * HI_HALF * 128};  // the same inside the AH unit
     const unsigned la_b[2] = {la0 + (wn & 1) * 64 * 128, (la0 ^ 64u) + (wn & 1) * 64 * 128};
     const int b_unit = 1 + (wn >> 1);
 
@@ -194,14 +204,14 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         };
         // rows of epilogue piece idx = pass*2 + it (pass = accumulator row tile mt, it = 8-row half of it), relative
         // to row_w: (mt >> 2) * 128 + (mt & 3) * 16 + it * 8
-#define QRB(idx) ((((idx) >> 3) * 128) + ((((idx) >> 1) & 3) * 16) + (((idx) & 1) * 8))
+#define QRB(idx) ((((idx) >> 3) * (128 - (TM == 224 ? wm * 16 : 0))) + ((((idx) >> 1) & 3) * 16) + (((idx) & 1) * 8))
         u32x4 sv[16];
         auto fetch_side = [&](int quarter) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = quarter * 4 + q;
                 const int rb = QRB(idx);
-                sv[idx] = buf_load16(side_rs(), rb < rows_left ? s_off : OOB, rb * lds_ * 2);
+                sv[idx] = buf_load16(side_rs(), (rb < rows_left && !(TM == 224 && idx >= 14)) ? s_off : OOB, rb * lds_ * 2);
             }
         };
         f32x4 acc[8][4];
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             bf16x8 af[4][2], bq[4][2];
             // (no s_setprio around the MFMAs: raising the computing wave's priority starved its SIMD partner's load slot,
             //  measured -4..6 % on the model's shapes; raising the loader's instead -4 %)
-            auto mma = [&](const int mt0) {
+            auto mma = [&](const int mt0, const int nmt) {
                 if (DBG & 2) {
 #pragma unroll
                     for (int kh = 0; kh < 2; ++kh)
@@ -233,27 +243,30 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t) {
+                        if (t >= nmt) continue;
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
                             acc[mt0 + t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt0 + t][nt], 0, 0, 0);
+                    }
             };
-            auto load_a = [&](const char* base) {
+            auto load_a = [&](const char* base, const unsigned (&la)[2], const int nmt) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    if (t >= nmt) continue;
                     if (DBG & 4) {
                         af[t][0] = __builtin_bit_cast(bf16x8, make_uint4(KT + t, lane, t, 1));
                         af[t][1] = __builtin_bit_cast(bf16x8, make_uint4(KT - t, lane, t, 2));
                     } else {
-                        af[t][0] = *reinterpret_cast<const bf16x8*>(base + la_a[0] + t * 2048);
-                        af[t][1] = *reinterpret_cast<const bf16x8*>(base + la_a[1] + t * 2048);
+                        af[t][0] = *reinterpret_cast<const bf16x8*>(base + la[0] + t * 2048);
+                        af[t][1] = *reinterpret_cast<const bf16x8*>(base + la[1] + t * 2048);
                     }
                 }
             };
             // ---- phase A: AL x B
             if (DBG & 64) __builtin_amdgcn_s_setprio(1);
             if (DBG & 32) { issue_pair(2); __builtin_amdgcn_sched_barrier(0); }
-            load_a(ua_lo);
+            load_a(ua_lo, la_a, 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (DBG & 4) {
@@ -276,12 +289,12 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
             if (DBG & 64) __builtin_amdgcn_s_setprio(0);
             slot_barrier();
-            mma(0);
+            mma(0, 4);
             slot_barrier();
             // ---- phase B: AH x B
             if (DBG & 64) __builtin_amdgcn_s_setprio(1);
             if (DBG & 32) { issue_pair(0); __builtin_amdgcn_sched_barrier(0); }
-            load_a(ua_hi);
+            load_a(ua_hi, la_h, NB);
             if (!(DBG & 32)) issue_pair(0);                                  // units U0+8, U0+9
             if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
             // units <= U0+6 (the next K tile's AL, BL, BH) landed; the side loads just issued are younger still
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             }
             if (DBG & 64) __builtin_amdgcn_s_setprio(0);
             slot_barrier();
-            mma(4);
+            mma(4, NB);
             slot_barrier();
             ++KT;
             U0 += 4;
@@ -325,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         const int re = lane_e & 15, ge = lane_e >> 4, rowe = lane_e >> 3, l7 = lane_e & 7;
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
+            if (TM == 224 && pass == 7) continue;       // the AH unit holds three row tiles per wavefront
             if (LATE_Q3 && pass == 2) fetch_side(2);
             if (LATE_Q3 && pass == 4) fetch_side(3);
             if (HAS_SIDE && (pass & 1) == 0) {

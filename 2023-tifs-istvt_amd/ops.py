@@ -170,6 +170,17 @@ class prof:
         return False
 
 
+_cus: dict = {}
+
+
+def _cu_count(device) -> int:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _cus:
+        n = torch.cuda.get_device_properties(idx).multi_processor_count
+        _cus[idx] = (n if n >= 8 else 256) & ~7
+    return _cus[idx]
+
+
 def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residual=None, bias=None, out_mode=0,
                      splitk=1, alpha=1.0) -> str:
     """which kernel istvt_gemm launches for these operands (mirrors the dispatch rule in csrc/gemm.hip; the names
@@ -183,7 +194,13 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
         if persistent:
             side = 'true' if (epi == 0 and residual is not None) else 'false'
             if q_ok and os.environ.get('ISTVT_GEMM_Q', '1') != '0':
-                return 'gemm256q_kernel<%d, %s, 0>' % (epi, side)
+                # row tile height as gemm.hip picks it: 256 unless ISTVT_GEMM_TM=224 (force) / -1 (rounds x height)
+                cus = _cu_count(A.device)
+                t256 = -(-M // 256) * -(-N // 256)
+                t224 = -(-M // 224) * -(-N // 256)
+                tm_env = int(os.environ.get('ISTVT_GEMM_TM', '0'))
+                use224 = tm_env == 224 or (tm_env == -1 and -(-t224 // cus) * 224 < -(-t256 // cus) * 256)
+                return 'gemm256q_kernel<%d, %s, 0, %d>' % (epi, side, 224 if use224 else 256)
             if K <= 96:
                 return 'gemm256r_kernel<false, 0>'
             return 'gemm256p_kernel<%d, %s>' % (epi, side)
