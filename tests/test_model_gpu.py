@@ -353,3 +353,17 @@ def test_early_all_reduce_two_ranks():
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count('early all-reduce used=True') == 2
+
+
+def test_gemm_224_row_tile_variant():
+    """The 224-row tile variant of the persistent GEMM (ISTVT_GEMM_TM=224, read once per process): every GEMM parity
+    check of tests/test_kernels_gpu.py again, in a child process with the variant forced."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_kernels_gpu.py'), '-q', '-x', '-m', 'gpu',
+                        '-k', 'gemm', '-p', 'no:cacheprovider'],
+                       env=dict(os.environ, ISTVT_GEMM_TM='224'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
