@@ -90,7 +90,8 @@ class GradBucket:
                 return
             if dist.get_world_size(group) == 1 or device != self.flat.device:
                 return
-            Fn.join_side_stream(device.index)           # the side-stream weight gradients are part of the slice
+            if device.type == 'cuda':
+                Fn.join_side_stream(device.index)       # the side-stream weight gradients are part of the slice
             self._early_work = dist.all_reduce(self.flat[lo:self.numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
 
         self._on_ready = on_ready

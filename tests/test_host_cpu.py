@@ -137,6 +137,19 @@ ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 1))
 ref.load_state_dict(lin.state_dict())
 torch.nn.functional.binary_cross_entropy_with_logits(ref(x).view(-1), y).backward()
 err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(lin.parameters(), ref.parameters()))
+# the same step with the all-reduce of the last layer's slice started early (the hook the token-assembly backward calls
+# on the GPU is invoked by hand here, between "its gradients are complete" and the end of backward)
+for p in params:
+    p._istvt_fused_grad = True
+bucket.enable_early_all_reduce(2)
+bucket.zero()
+torch.nn.functional.binary_cross_entropy_with_logits(lin(xs).view(-1), ys).backward()
+bucket._on_ready(bucket.flat.device)
+early_used = bucket._early_work is not None
+bucket.all_reduce()
+bucket.disable_early_all_reduce()
+err_early = max(float((p.grad - q.grad).abs().max()) for p, q in zip(lin.parameters(), ref.parameters()))
+err = max(err, err_early) if early_used else 1.0
 w0 = [float(p.detach().sum()) for p in lin.parameters()]
 out = torch.tensor(w0); gathered = [torch.zeros_like(out) for _ in range(world)]
 dist.all_gather(gathered, out)
