@@ -205,7 +205,9 @@ def main():
             d[3] += 1
         kern = {k: {'ms_per_step': round(v[0] * 1e3, 3), 'launches': v[3], 'GBps': round(v[1] / v[0] / 1e9, 1),
                     'frac_hbm_peak': round(v[1] / v[0] / 1e9 / PEAK_HBM_GBPS, 3),
-                    **({'TFLOPs': round(v[2] / v[0] / 1e12, 2)} if k.startswith('attn_spatial') else {})}
+                    **({'TFLOPs': round(v[2] / v[0] / 1e12, 2),
+                        'frac_mfma_peak': round(v[2] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4)}      # BASELINE.json: "attn MFMA util %"
+                       if k.startswith('attn_spatial') else {})}
                 for k, v in agg.items() if v[0] > 0}
         by = {}                                   # rocprof kernel name -> [flops, seconds, launches]
         for ev0, ev1, flops, variant, shape, kname in recs:
