@@ -33,7 +33,8 @@ SIGNATURES = {
     'istvt_bn_finalize': [P, P, ctypes.c_double, P, P, P, P, F, F, P, I, I, I, P],
     'istvt_bn_apply': [P, P, P, L, I, I, I, P],
     'istvt_bn_bwd_stats': [P, P, P, P, P, L, I, I, P],
-    'istvt_bn_bwd_apply': [P, P, P, P, P, P, P, P, P, L, I, I, P],
+    'istvt_bn_bwd_apply': [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    'istvt_bn_add_fwd': [P, P, P, P, P, L, I, I, P],
     'istvt_im2col_conv1': [P, P, I, I, I, P],
     'istvt_conv1_fwd': [P, P, P, I, I, I, P],
     'istvt_conv1_wgrad': [P, P, P, P, I, I, I, P],
@@ -55,8 +56,17 @@ SIGNATURES = {
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
     'istvt_cast_transpose': [P, L, P, L, P, L, I, I, P],
-    'istvt_sgd_momentum': [P, P, P, L, F, F, F, F, I, I, I, P],
-    'istvt_adamw': [P, P, P, P, L, F, F, F, F, F, L, I, P],
+    'istvt_relu_avgpool_fwd': [P, P, I, I, I, I, I, P],
+    'istvt_relu_avgpool_bwd': [P, P, P, I, I, I, I, I, P],
+    'istvt_prepend_fwd': [P, P, P, P, L, L, I, I, I, I, I, P],
+    'istvt_prepend_bwd': [P, L, P, P, P, L, I, I, I, I, I, P],
+    'istvt_seq_mean_fwd': [P, L, P, L, I, I, I, P],
+    'istvt_seq_mean_bwd': [P, P, L, L, I, I, I, P],
+    'istvt_dropout_fwd': [P, L, P, L, P, L, I, F, ctypes.c_ulonglong, I, P],
+    'istvt_dropout_bwd': [P, L, P, P, L, L, I, F, I, P],
+    'istvt_add': [P, L, P, L, P, L, L, I, I, P],
+    'istvt_sgd_momentum': [P, P, P, L, F, F, F, F, I, I, I, F, P],
+    'istvt_adamw': [P, P, P, P, L, F, F, F, F, F, L, I, F, P],
 }
 
 _lib = None

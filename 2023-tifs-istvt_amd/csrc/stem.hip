@@ -190,10 +190,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ bnp,
                                                            const float* __restrict__ gamma, const double* s1,
                                                            const double* s2, T* __restrict__ du, float* dgamma,
-                                                           float* dbeta, long M, int C) {
+                                                           float* dbeta, long M, int C, int batch_stats) {
     const int vpr = C / 8;
     const long nvec = M * vpr, stride = (long)gridDim.x * 256;
-    const float invM = 1.0f / (float)M;
+    // eval mode (running statistics are constants): du = gamma * rstd * dz, no mean / projection terms
+    const float invM = batch_stats ? 1.0f / (float)M : 0.0f;
     const float* mean = bnp;
     const float* rstd = bnp + C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
@@ -216,6 +217,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (dgamma) dgamma[c] += (float)s2[c];
             if (dbeta) dbeta[c] += (float)s1[c];
         }
+    }
+}
+
+// out = bn_x(x) + (bns ? bn_s(skip) : skip): the tail of a stride-1 Block (xception.py:91-100, no MaxPool)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_add_kernel(const T* __restrict__ x, const float* __restrict__ bnx,
+                                                     const T* __restrict__ skip, const float* __restrict__ bns,
+                                                     T* __restrict__ out, long M, int C) {
+    const int vpr = C / 8;
+    const long nvec = M * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        const int c0 = (int)(i % vpr) * 8;
+        float v[8], sv[8];
+        load8(x + i * 8, v);
+        load8(skip + i * 8, sv);
+        bn_affine8(v, bnx, C, c0);
+        if (bns) bn_affine8(sv, bns, C, c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(v[j])) + sv[j];     // the value a separate BN pass would store
+        store8(out + i * 8, v);
     }
 }
 
@@ -252,6 +273,14 @@ extern "C" int istvt_bn_apply(const void* x, const float* bnp, void* y, long M, 
     return istvt_check_launch();
 }
 
+extern "C" int istvt_bn_add_fwd(const void* x, const float* bnx, const void* skip, const float* bns, void* out, long M,
+                                int C, int dtype, hipStream_t stream) {
+    if (M <= 0 || C % 8 != 0 || !bnx) return ISTVT_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_add_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0, stream,
+                                             (const T*)x, bnx, (const T*)skip, bns, (T*)out, M, C));
+    return istvt_check_launch();
+}
+
 extern "C" int istvt_bn_bwd_stats(const void* dz, const void* u, const float* bnp, double* s1, double* s2, long M,
                                   int C, int dtype, hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
@@ -264,11 +293,11 @@ extern "C" int istvt_bn_bwd_stats(const void* dz, const void* u, const float* bn
 
 extern "C" int istvt_bn_bwd_apply(const void* dz, const void* u, const float* bnp,
                                   const float* gamma, const double* s1, const double* s2, void* du, float* dgamma,
-                                  float* dbeta, long M, int C, int dtype, hipStream_t stream) {
+                                  float* dbeta, long M, int C, int batch_stats, int dtype, hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0,
                                              stream, (const T*)dz, (const T*)u, bnp, gamma, s1, s2, (T*)du,
-                                             dgamma, dbeta, M, C));
+                                             dgamma, dbeta, M, C, batch_stats));
     return istvt_check_launch();
 }
 
@@ -448,7 +477,7 @@ struct DwArgs {
     int flip;                                                        // 1: correlate with flipped taps (input gradient)
     const void* msrc; const float* m_bn;                             // ReLU mask source (+ optional BatchNorm pack)
     int mask_pre, mask_post;
-    const void* addsrc; int Ha, Wa;                                  // += addsrc[f][y/2][x/2] at even (y,x)
+    const void* addsrc; int Ha, Wa;                                  // += addsrc[f][y/2][x/2] at even (y,x); Ha == H && Wa == W: += addsrc[f][y][x]
     double* st_s1; double* st_s2;                                    // fused BN-backward statistics (of m_bn)
     unsigned long long* dbg;                                         // diagnostic builds only (-DISTVT_DW_DIAG)
 };
@@ -527,6 +556,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     // epilogue operands (ReLU-mask source, stride-2 skip gradient) of this thread's four outputs: requested BEFORE the
     // tile is staged -- loaded per item after the barrier they were dependent HBM latencies inside the convolution
     typename Mma<T>::frag mraw[DW_ITEMS], araw[DW_ITEMS];
+    // stride-1 blocks (identity or 1x1 skip, xception.py:97-100) add the skip-path gradient at every pixel
+    const bool addfull = EPI && p.Ha == p.H && p.Wa == p.W;
+    const int ashift = addfull ? 0 : 1;
     if constexpr (EPI) {
         const int cq = c0 + (tid % DW_NCH) * 8;
 #pragma unroll
@@ -536,8 +568,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
             mraw[k] = Mma<T>::zero(); araw[k] = Mma<T>::zero();
             if (y < p.H && x < p.W && cq < p.C) {
                 if (p.msrc) mraw[k] = frag_load((const T*)p.msrc + ((f * p.H + y) * p.W + x) * p.C + cq);
-                if (p.addsrc && !(y & 1) && !(x & 1))
-                    araw[k] = frag_load((const T*)p.addsrc + ((f * p.Ha + (y >> 1)) * p.Wa + (x >> 1)) * p.C + cq);
+                if (p.addsrc && (addfull || (!(y & 1) && !(x & 1))))
+                    araw[k] = frag_load((const T*)p.addsrc + ((f * p.Ha + (y >> ashift)) * p.Wa + (x >> ashift)) * p.C + cq);
             }
         }
     }
@@ -604,7 +636,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = z[j] > 0.f ? acc[j] : 0.f;
         }
-        if (p.addsrc && !(y & 1) && !(x & 1)) {
+        if (p.addsrc && (addfull || (!(y & 1) && !(x & 1)))) {
             float a[8];
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -765,7 +797,7 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     if ((mask_pre || mask_post || st_s1) && !msrc) return ISTVT_ERR_SHAPE;
     if (st_s1 && !m_bn) return ISTVT_ERR_SHAPE;
-    if (addsrc && (Ha != (H - 1) / 2 + 1 || Wa != (W - 1) / 2 + 1)) return ISTVT_ERR_SHAPE;
+    if (addsrc && !(Ha == H && Wa == W) && (Ha != (H - 1) / 2 + 1 || Wa != (W - 1) / 2 + 1)) return ISTVT_ERR_SHAPE;
     DwArgs a;
     a.in = in; a.w = w; a.out = out; a.Fr = Fr; a.H = H; a.W = W; a.C = C;
     a.in_bn = in_bn; a.in_relu = in_relu; a.flip = flip;

@@ -146,15 +146,41 @@ def join_side_stream(dev=None):
 grad_ready_hooks = []
 
 
-def _join_side(dev):
-    main = _overlap['pending'].pop(dev, None)
-    if main is not None:
-        main.wait_stream(_overlap['streams'][dev])
+def _join_side(dev, task=None):
+    """task: the autograd graph task whose end-of-backward callback this is (None: join whatever is pending).  A
+    callback of an EARLIER task whose entry has already been flushed and replaced must not touch the new entry."""
+    ent = _overlap['pending'].get(dev)
+    if ent is None or (task is not None and ent[1] != task):
+        return
+    del _overlap['pending'][dev]
+    ent[0].wait_stream(_overlap['streams'][dev])
     # The operands of the side-stream launches were kept alive until here instead of being handed to the allocator with
     # record_stream(): blocks parked behind side-stream events made the caching allocator grow by a run-dependent
     # 16-56 GB at C2 (reserved 47-87 GB against 31 GB single-stream).  Released after the join they go back to the main
     # stream's pool in order: ~10 GB more at the peak, the same every run.
     _overlap['keep'].pop(dev, None)
+
+
+def _graph_task() -> int:
+    return torch._C._current_graph_task_id()
+
+
+def flush_stale_joins():
+    """A backward pass that aborted (an exception in a later node, an out-of-memory error) never runs its
+    end-of-backward callback: its join entry and the operands it keeps alive would stay behind, every later backward
+    would skip registering a join and the optimizer would read weight gradients the side stream may still be writing.
+    Called from the forward (outside any backward every entry is stale) and from _wgrad (an entry of another graph
+    task is stale): joins the side stream into the CURRENT stream and drops the entry."""
+    if not _overlap['pending']:
+        return
+    task = _graph_task()
+    for dev in list(_overlap['pending']):
+        if task == -1 or _overlap['pending'][dev][1] != task:
+            side = _overlap['streams'].get(dev)
+            if side is not None:
+                torch.cuda.current_stream(torch.device('cuda', dev)).wait_stream(side)
+            del _overlap['pending'][dev]
+            _overlap['keep'].pop(dev, None)
 
 
 def _wgrad(dy, x, weight):
@@ -168,9 +194,14 @@ def _wgrad(dy, x, weight):
     if side is None:
         side = _overlap['streams'][dev] = torch.cuda.Stream(device=dy.device, priority=int(os.environ.get('ISTVT_WGRAD_PRIO', '0')))
     main = torch.cuda.current_stream(dy.device)
-    if dev not in _overlap['pending']:
-        _overlap['pending'][dev] = main
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
+    task = _graph_task()
+    ent = _overlap['pending'].get(dev)
+    if ent is not None and ent[1] != task:
+        flush_stale_joins()                      # left behind by a backward pass that never finished
+        ent = None
+    if ent is None:
+        _overlap['pending'][dev] = (main, task)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev, task))
     side.wait_stream(main)
     with torch.cuda.stream(side):
         ops.linear_wgrad(dy, x, out=out)
@@ -200,6 +231,8 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, defer_bias=False):
         """defer_bias: the LayerNorm that consumes y accumulates the bias gradient (BiasSink); skip it here."""
+        if _overlap['pending']:
+            flush_stale_joins()
         w = ops.weight_as(weight, x.dtype, pad=True)
         y = ops.linear_fwd(x, w, bias, residual, pad=True)
         ctx.save_for_backward(x, weight, bias)
@@ -318,6 +351,203 @@ class TakeClsFn(Function):
         dx = ops.zeros_rows(B * F * P, D, dtype, g.device)
         dx.view(B, F, P, D)[:, 0, 0] = g
         return dx.view(B, F * P, D), None, None, None
+
+
+def _new_seed() -> int:
+    """63-bit Philox key from torch's default CPU generator (torch.manual_seed makes a run reproducible)"""
+    return int(torch.empty((), dtype=torch.int64).random_()) & 0x7fffffffffffffff
+
+
+def _dropout_fwd(x: Tensor, p: float, seed: int):
+    from . import _lib
+    x2, ldx = ops.rows(ops._req(x))
+    M, D = x2.shape
+    y = ops.empty_rows(M, D, x.dtype, x.device, pad=(ldx != D))
+    mask = torch.empty((M, D), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().istvt_dropout_fwd(x2.data_ptr(), ldx, y.data_ptr(), y.stride(0) if M > 1 else D, mask.data_ptr(),
+                                            M, D, float(p), int(seed), ops.dtype_code(x), ops._stream()), 'istvt_dropout_fwd')
+    return y, mask
+
+
+def _dropout_bwd(dy: Tensor, mask: Tensor, p: float) -> Tensor:
+    from . import _lib
+    dy2, ldy = ops.rows(dy)
+    M, D = dy2.shape
+    dx = ops.empty_rows(M, D, dy.dtype, dy.device, pad=(ldy != D))
+    _lib.check(_lib.lib().istvt_dropout_bwd(dy2.data_ptr(), ldy, mask.data_ptr(), dx.data_ptr(), dx.stride(0) if M > 1 else D,
+                                            M, D, float(p), ops.dtype_code(dy), ops._stream()), 'istvt_dropout_bwd')
+    return dx
+
+
+class DropoutFn(Function):
+    """nn.Dropout(p) in training mode on [M, D] rows (module.py:29,31,78,187; models_copy.py:41-44).  The mask comes
+    from a Philox4x32-10 stream keyed by `seed`; it cannot reproduce torch's own dropout mask bit for bit -- parity is
+    distributional (keep rate, 1/(1-p) scaling) plus exact mask consistency between forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        y, mask = _dropout_fwd(x, p, seed)
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return _dropout_bwd(dy, mask, ctx.p), None, None
+
+
+def dropout(x: Tensor, p: float, training: bool = True) -> Tensor:
+    """F.dropout(x, p, training) on the last dim's rows; identity when p == 0 or not training."""
+    if p == 0.0 or not training:
+        return x
+    if not 0.0 <= p < 1.0:
+        raise ValueError('dropout probability has to be in [0, 1), got %r' % (p,))
+    if x.shape[-1] % 8:
+        raise RuntimeError('dropout rows must be a multiple of 8 wide, got %d' % x.shape[-1])
+    y = DropoutFn.apply(x.reshape(-1, x.shape[-1]), p, _new_seed())
+    return y.reshape(*x.shape[:-1], x.shape[-1])
+
+
+class AddFn(Function):
+    """a + b on [M, D] rows (the residual add that cannot ride in a GEMM epilogue because a Dropout sits in between)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from . import _lib
+        (a2, lda), (b2, ldb) = ops.rows(ops._req(a)), ops.rows(ops._req(b))
+        M, D = a2.shape
+        out = ops.empty_rows(M, D, a.dtype, a.device, pad=(lda != D))
+        _lib.check(_lib.lib().istvt_add(a2.data_ptr(), lda, b2.data_ptr(), ldb, out.data_ptr(), out.stride(0) if M > 1 else D,
+                                        M, D, ops.dtype_code(a), ops._stream()), 'istvt_add')
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise RuntimeError('add: operands must match (%s %s vs %s %s)' % (tuple(a.shape), a.dtype, tuple(b.shape), b.dtype))
+    y = AddFn.apply(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]))
+    return y.reshape(a.shape)
+
+
+class FeedForwardDropFn(Function):
+    """FeedForward with active dropouts (module.py:26-32 with dropout > 0, training): Linear -> GELU -> Dropout ->
+    Linear -> Dropout.  The dropout masks are elementwise factors, so the backward still uses the GEMM whose epilogue
+    multiplies by gelu'(u), and applies the first dropout's mask to its result."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p1, p2, seed1, seed2):
+        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True)
+        m1 = m2 = None
+        if p1 > 0:
+            g, m1 = _dropout_fwd(g, p1, seed1)
+        y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype, pad=True), b2, None, pad=True)
+        if p2 > 0:
+            y, m2 = _dropout_fwd(y, p2, seed2)
+        ctx.save_for_backward(x, u, g, w1, b1, w2, b2, m1, m2)
+        ctx.p = (float(p1), float(p2))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, u, g, w1, b1, w2, b2, m1, m2 = ctx.saved_tensors
+        p1, p2 = ctx.p
+        if m2 is not None:
+            dy = _dropout_bwd(dy, m2, p2)
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True)
+        if m1 is not None:
+            du = _dropout_bwd(du, m1, p1)
+        dw2 = _wgrad(dy, g, w2)
+        db2 = _bgrad(dy, b2)
+        dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype, pad=True), pad=True) if ctx.needs_input_grad[0] else None
+        dw1 = _wgrad(du, x, w1)
+        db1 = _bgrad(du, b1)
+        return dx, dw1, db1, dw2, db2, None, None, None, None
+
+
+class PrependFn(Function):
+    """Token assembly of the ablation transformers (vivit.py:60-67 ViViT space stage, :74-75 its temporal stage,
+    :183-186 VanillaTr): out[s] = [tok | src[s]] (+ pos[s % period]).  src [S, n, D]; tok (1, 1, D) float32;
+    pos float32 [period, pos_rows >= n + 1, D] or None."""
+
+    @staticmethod
+    def forward(ctx, src, tok, pos, period):
+        from . import _lib
+        src = ops._c(ops._req(src))
+        S, n, D = src.shape
+        if pos is not None and (pos.shape[-1] != D or pos.shape[-2] < n + 1):
+            raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1'
+                               % (n + 1, pos.shape[-2]))
+        out = ops.empty_rows(S * (n + 1), D, src.dtype, src.device, True)
+        pos_rows = pos.shape[-2] if pos is not None else 0
+        _lib.check(_lib.lib().istvt_prepend_fwd(src.data_ptr(), tok.data_ptr(), ops._ptr(pos), out.data_ptr(), out.stride(0),
+                                                S, n, D, period, pos_rows, ops.dtype_code(src), ops._stream()), 'istvt_prepend_fwd')
+        ctx.save_for_backward(tok, pos)
+        ctx.geom = (S, n, D, period, pos_rows)
+        return out.view(S, n + 1, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        from . import _lib
+        tok, pos = ctx.saved_tensors
+        S, n, D, period, pos_rows = ctx.geom
+        d2, ldd = ops.rows(dout.reshape(S * (n + 1), D))
+        dsrc = torch.empty((S, n, D), dtype=dout.dtype, device=dout.device) if ctx.needs_input_grad[0] else None
+        (dt, rt), (dp, rp) = _target(tok), _target(pos)
+        _lib.check(_lib.lib().istvt_prepend_bwd(d2.data_ptr(), ldd, ops._ptr(dsrc), dt.data_ptr(), ops._ptr(dp), S, n, D, period,
+                                                pos_rows, ops.dtype_code(d2), ops._stream()), 'istvt_prepend_bwd')
+        return dsrc, rt, rp, None
+
+
+class TakeFirstFn(Function):
+    """x[:, 0] of [S, n, D] (the cls rows, vivit.py:71,79,189); backward scatters into a zeroed, line-aligned buffer."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.geom = (tuple(x.shape), x.dtype)
+        return x[:, 0].contiguous()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (S, n, D), dtype = ctx.geom
+        dx = ops.zeros_rows(S * n, D, dtype, g.device)
+        dx.view(S, n, D)[:, 0] = g
+        return dx.view(S, n, D)
+
+
+class SeqMeanFn(Function):
+    """x.mean(dim=1) of [S, n, D] (ViViT pool='mean', vivit.py:79)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        S, n, D = x.shape
+        x2, ldx = ops.rows(ops._req(x).reshape(S * n, D))
+        out = torch.empty((S, D), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().istvt_seq_mean_fwd(x2.data_ptr(), ldx, out.data_ptr(), S, n, D, ops.dtype_code(x), ops._stream()),
+                   'istvt_seq_mean_fwd')
+        ctx.geom = (S, n, D)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        from . import _lib
+        S, n, D = ctx.geom
+        g = ops._c(g)
+        dx = ops.empty_rows(S * n, D, g.dtype, g.device, True)
+        _lib.check(_lib.lib().istvt_seq_mean_bwd(g.data_ptr(), dx.data_ptr(), dx.stride(0), S, n, D, ops.dtype_code(g),
+                                                 ops._stream()), 'istvt_seq_mean_bwd')
+        return dx.view(S, n, D)
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, fork=False, sink=None):

@@ -1,9 +1,11 @@
 """Transformer sub-modules of ISTVT with the reference's constructor/forward signatures and
 parameter names (reference: network/vivit/module.py), executing on hand-written HIP kernels.
 
-Only the four modules on the hot path exist here: PreNorm (module.py:15-21), FeedForward
-(:23-34), SpatialOnlyAttention (:66-93), TemporalResidualAttention (:174-208).  The tokens-per-
-frame count the reference hard-codes as ``19 * 19 + 1`` is the ``hw`` keyword (default 362).
+The four modules on the hot path: PreNorm (module.py:15-21), FeedForward (:23-34), SpatialOnlyAttention
+(:66-93), TemporalResidualAttention (:174-208); and the ablation siblings: Attention (:36-64) and
+TemporalOnlyAttention (:145-172), which are the same two attention kernels under other index maps (one "frame" of
+all n tokens; one packed to_qkv and no frame difference).  The tokens-per-frame count the reference hard-codes as
+``19 * 19 + 1`` is the ``hw`` keyword (default 362).
 
 All forwards take ``(b, n, dim)`` float32 or bfloat16 tensors on a ROCm device.  Extra keyword
 arguments (``hw=``, ``residual=``) travel through PreNorm's ``**kwargs`` exactly like the
@@ -25,8 +27,8 @@ def _frames(n, hw, what):
 
 
 def _dropout(seq, y):
-    p = seq[1].p
-    return y if (p == 0.0 or not seq[1].training) else nn.functional.dropout(y, p, True)
+    """the nn.Dropout that follows an output projection (module.py:78,187), on the HIP dropout kernel"""
+    return Fn.dropout(y, seq[1].p, seq[1].training)
 
 
 class PreNorm(nn.Module):
@@ -74,11 +76,16 @@ class FeedForward(nn.Module):
 
     def forward(self, x, residual=None, defer_bias=False):
         fc1, fc2 = self.net[0], self.net[3]
-        if self.training and (self.net[2].p > 0 or self.net[4].p > 0):
-            raise NotImplementedError('FeedForward with dropout > 0 in training mode is not on the ISTVT hot path')
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         r2 = residual.reshape(-1, fc2.out_features) if residual is not None else None
+        if self.training and (self.net[2].p > 0 or self.net[4].p > 0):
+            # dropout > 0 (reference default is 0): the unfused chain Linear+GELU -> Dropout -> Linear -> Dropout (+ residual)
+            y = Fn.FeedForwardDropFn.apply(x2, fc1.weight, fc1.bias, fc2.weight, fc2.bias, self.net[2].p, self.net[4].p,
+                                           Fn._new_seed(), Fn._new_seed())
+            if r2 is not None:
+                y = Fn.add(y, r2)
+            return y.view(*lead, fc2.out_features)
         y = Fn.FeedForwardFn.apply(x2, fc1.weight, fc1.bias, fc2.weight, fc2.bias, r2, defer_bias)
         return y.view(*lead, fc2.out_features)
 
@@ -112,7 +119,7 @@ class SpatialOnlyAttention(nn.Module):
         if not plain:
             y = _dropout(self.to_out, y)
             if residual is not None:
-                y = y + residual
+                y = Fn.add(y, residual)
         return y
 
 
@@ -142,7 +149,7 @@ class TemporalResidualAttention(nn.Module):
         if not plain:
             y = _dropout(self.to_out, y)
             if residual is not None:
-                y = y + residual
+                y = Fn.add(y, residual)
         return y
 
     def forward(self, x, hw=None, residual=None, defer_bias=False):
@@ -161,3 +168,78 @@ class TemporalResidualAttention(nn.Module):
         outs = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw, fork, sink)
         y = self._attend(outs[0], outs[1], b, n, hw, frames, residual, defer_bias)
         return (y, outs[2].view(b, n, d)) if fork else y
+
+
+class Attention(nn.Module):
+    """Plain multi-head self-attention over all n tokens of each sequence (reference module.py:36-64): the spatial
+    attention kernel with one "frame" per sequence."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(
+            nn.Linear(inner_dim, dim),
+            nn.Dropout(dropout)
+        ) if project_out else nn.Identity()
+
+    def forward(self, x, residual=None):
+        b, n, _ = x.shape
+        qkv = Fn.LinearFn.apply(x.reshape(b * n, -1), self.to_qkv.weight, None, None)
+        out = Fn.SpatialAttnFn.apply(qkv, b, n, self.heads, self.dim_head, False)
+        if isinstance(self.to_out, nn.Identity):
+            y = out.view(b, n, -1)
+            return y if residual is None else Fn.add(y, residual)
+        proj = self.to_out[0]
+        plain = self.to_out[1].p == 0.0 or not self.training
+        r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
+        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2).view(b, n, -1)
+        if not plain:
+            y = _dropout(self.to_out, y)
+            if residual is not None:
+                y = Fn.add(y, residual)
+        return y
+
+
+class TemporalOnlyAttention(nn.Module):
+    """Attention over the frame axis per (batch, head, position) from ONE packed to_qkv, no frame difference
+    (reference module.py:145-172; its hard-coded ``hw = 19 * 19 + 1`` is the ``hw`` keyword).  The temporal
+    attention kernel takes q|k and v as two matrices: they come from two GEMMs over the two row blocks of
+    ``to_qkv.weight`` (views of the one parameter, so the state dict and the gradient are the reference's)."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0., hw=19 * 19 + 1):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.hw = hw
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(
+            nn.Linear(inner_dim, dim),
+            nn.Dropout(dropout)
+        )
+
+    def forward(self, x, hw=None, residual=None):
+        b, n, d = x.shape
+        hw = self.hw if hw is None else hw
+        frames = _frames(n, hw, 'TemporalOnlyAttention')
+        inner = self.heads * self.dim_head
+        x2 = x.reshape(b * n, d)
+        w = self.to_qkv.weight
+        qk = Fn.LinearFn.apply(x2, w[:2 * inner], None, None)
+        v = Fn.LinearFn.apply(x2, w[2 * inner:], None, None)
+        out = Fn.TemporalAttnFn.apply(qk, v, b, frames, hw, self.heads, self.dim_head)
+        proj = self.to_out[0]
+        plain = self.to_out[1].p == 0.0 or not self.training
+        r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
+        y = Fn.LinearFn.apply(out, proj.weight, proj.bias, r2).view(b, n, -1)
+        if not plain:
+            y = _dropout(self.to_out, y)
+            if residual is not None:
+                y = Fn.add(y, residual)
+        return y

@@ -11,7 +11,30 @@ from torch import nn
 
 from istvt_amd import functional as Fn
 from istvt_amd import ops
-from .module import PreNorm, FeedForward, SpatialOnlyAttention, TemporalResidualAttention
+from .module import (Attention, PreNorm, FeedForward, SpatialOnlyAttention, TemporalOnlyAttention,  # noqa: F401
+                     TemporalResidualAttention)
+
+
+class Transformer(nn.Module):
+    """Reference vivit.py:10-25 (the ablation baselines' encoder): x = attn(LN(x)) + x ; x = ff(LN(x)) + x ; LN."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        self.norm = nn.LayerNorm(dim)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))
+            ]))
+
+    def forward(self, x):
+        # both residual adds ride in the epilogue of the block's last GEMM; the residual's gradient is summed inside
+        # the LayerNorm backward kernel (PreNorm residual='input')
+        for attn, ff in self.layers:
+            x = attn(x, residual='input')
+            x = ff(x, residual='input')
+        return Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
 class STTransformer(nn.Module):
@@ -126,3 +149,93 @@ class XceptionVidTr(nn.Module):
         feats = self.xcep.model.low_level_features_nhwc(x.flatten(0, 1), self.compute_dtype)   # (b*t, h, w, c)
         n, h, w, c = feats.shape
         return self.vit.forward_features(feats.view(b, t, h * w, c))
+
+
+def _head(mlp_head, x):
+    ln, fc = mlp_head[0], mlp_head[1]
+    y = Fn.layer_norm(x, ln.weight, ln.bias, ln.eps)
+    return Fn.LinearFn.apply(y, fc.weight, fc.bias, None).float()
+
+
+class ViViT(nn.Module):
+    """Reference vivit.py:29-81 (factorised-encoder ablation): a space transformer per frame over
+    [space_token | patches] + pos, whose cls rows -> [temporal_token | frames] -> temporal transformer -> cls / mean
+    -> mlp_head.  (patch_size must be 1: the reference's patch Linear is commented out, vivit.py:40-43.)"""
+
+    def __init__(self, image_size, patch_size, num_classes, num_frames, dim=728, depth=12, heads=8, pool='cls',
+                 in_channels=728, dim_head=64, dropout=0., emb_dropout=0., scale_dim=4, compute_dtype=torch.float32):
+        super().__init__()
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
+        num_patches = (image_size // patch_size) ** 2
+        self.patch_size = patch_size
+        self.to_patch_embedding = nn.Sequential()          # the reference's Rearrange has no parameters
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_frames, num_patches + 1, dim))
+        self.space_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.space_transformer = Transformer(dim, depth, heads, dim_head, dim * scale_dim, dropout)
+        self.temporal_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.temporal_transformer = Transformer(dim, depth, heads, dim_head, dim * scale_dim, dropout)
+        self.dropout = nn.Dropout(emb_dropout)
+        self.pool = pool
+        self.mlp_head = nn.Sequential(
+            nn.LayerNorm(dim),
+            nn.Linear(dim, num_classes)
+        )
+        self.compute_dtype = compute_dtype
+
+    def forward(self, x):
+        """x: (b, t, c, h, w)"""
+        if self.patch_size != 1:
+            raise NotImplementedError('ViViT patch_size > 1 (the reference never projects the patches, vivit.py:42)')
+        b, t, c, h, w = x.shape
+        if t != self.pos_embedding.shape[1]:
+            raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1'
+                               % (t, self.pos_embedding.shape[1]))
+        feats = ops.cast(x.flatten(3).transpose(2, 3).contiguous(), self.compute_dtype).view(b * t, h * w, c)
+        xs = Fn.PrependFn.apply(feats, self.space_token, self.pos_embedding, t)           # (b t) (n+1) d
+        xs = Fn.dropout(xs, self.dropout.p, self.dropout.training)
+        xs = self.space_transformer(xs)
+        cls = Fn.TakeFirstFn.apply(xs).view(b, t, c)
+        xt = Fn.PrependFn.apply(cls, self.temporal_token, None, 1)                         # b (t+1) d
+        xt = self.temporal_transformer(xt)
+        y = Fn.SeqMeanFn.apply(xt) if self.pool == 'mean' else Fn.TakeFirstFn.apply(xt)
+        return _head(self.mlp_head, y)
+
+
+class VanillaTr(nn.Module):
+    """Reference vivit.py:150-191 (joint space-time ablation): Linear patch embedding of every (frame, position), one
+    cls token, one transformer over all t*h*w + 1 tokens."""
+
+    def __init__(self, image_size, patch_size, num_classes, num_frames, dim=728, depth=12, heads=8, pool='cls',
+                 in_channels=728, dim_head=64, dropout=0., emb_dropout=0., scale_dim=4, compute_dtype=torch.float32):
+        super().__init__()
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        assert image_size % patch_size == 0, 'Image dimensions must be divisible by the patch size.'
+        num_patches = (image_size // patch_size) ** 2
+        patch_dim = in_channels * patch_size ** 2
+        # index 1 is the Linear, as in the reference's Sequential(Rearrange, Linear, Rearrange): same state-dict key
+        self.to_patch_embedding = nn.Sequential(nn.Identity(), nn.Linear(patch_dim, dim), nn.Identity())
+        self.pos_embedding = nn.Parameter(torch.randn(1, (num_frames * num_patches) + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.transformer = Transformer(dim, depth, heads, dim_head, dim * scale_dim, dropout)
+        self.dropout = nn.Dropout(emb_dropout)      # constructed, never applied (as in the reference)
+        self.pool = pool
+        self.mlp_head = nn.Sequential(
+            nn.LayerNorm(dim),
+            nn.Linear(dim, num_classes)
+        )
+        self.compute_dtype = compute_dtype
+
+    def forward(self, x):
+        b, t, c, h, w = x.shape
+        fc = self.to_patch_embedding[1]
+        feats = ops.cast(x.flatten(3).transpose(2, 3).contiguous(), self.compute_dtype).view(b * t * h * w, c)
+        emb = Fn.LinearFn.apply(feats, fc.weight, fc.bias, None)
+        n = t * h * w
+        if n + 1 != self.pos_embedding.shape[1]:
+            raise RuntimeError('The size of tensor a (%d) must match the size of tensor b (%d) at non-singleton dimension 1'
+                               % (n + 1, self.pos_embedding.shape[1]))
+        emb = emb.reshape(b, n, -1)
+        xs = Fn.PrependFn.apply(emb, self.cls_token, self.pos_embedding, 1)
+        xs = self.transformer(xs)
+        return _head(self.mlp_head, Fn.TakeFirstFn.apply(xs))

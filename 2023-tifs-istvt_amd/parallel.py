@@ -12,6 +12,7 @@ parameters (block4..fc) that ``low_level_features`` never touches.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Tuple
 
 import torch
@@ -55,6 +56,11 @@ class GradBucket:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        self.defer_scale = False        # set by the fused optimizers: all_reduce() then only sums, the step kernel scales
+        self.grad_scale = 1.0           # what the next fused optimizer step multiplies the gradients by (1 / world size)
+        self._early = None
+        self._early_work = None
+        self._on_ready = None
         self.flat_params = None
         if flatten_params:
             if any(p.dtype != torch.float32 for p in self.params):
@@ -82,42 +88,68 @@ class GradBucket:
         if not all(getattr(p, '_istvt_fused_grad', False) for p in self.params[first_param:]):
             raise ValueError('enable_early_all_reduce needs GradBucket(..., fuse_accumulate=True)')
         lo = sum(p.numel() for p in self.params[:first_param])
-        self._early = (lo, self.numel, group)
         self._early_work = None
+        self.disable_early_all_reduce()
+        self._early = (lo, self.numel, group)
+        ref = weakref.ref(self)          # the global hook list must not keep a dropped bucket (and its collectives) alive
 
         def on_ready(device):
-            if self._early_work is not None or not (dist.is_available() and dist.is_initialized()):
+            me = ref()
+            if me is None:
+                if on_ready in Fn.grad_ready_hooks:
+                    Fn.grad_ready_hooks.remove(on_ready)
                 return
-            if dist.get_world_size(group) == 1 or device != self.flat.device:
+            if not (dist.is_available() and dist.is_initialized()):
                 return
+            if dist.get_world_size(group) == 1 or device != me.flat.device:
+                return
+            if me._early_work is not None:
+                # a second backward before all_reduce() (gradient accumulation): its kernels would add into the slice
+                # while the asynchronous collective is still reducing it, and its gradients would never be summed
+                raise RuntimeError('GradBucket: early all-reduce still in flight; there must be exactly one backward per '
+                                   'all_reduce() (call disable_early_all_reduce() for gradient accumulation)')
             if device.type == 'cuda':
                 Fn.join_side_stream(device.index)       # the side-stream weight gradients are part of the slice
-            self._early_work = dist.all_reduce(self.flat[lo:self.numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            me._early_work = dist.all_reduce(me.flat[lo:me.numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
 
         self._on_ready = on_ready
         Fn.grad_ready_hooks.append(on_ready)
 
     def disable_early_all_reduce(self):
         from . import functional as Fn
-        if getattr(self, '_on_ready', None) in Fn.grad_ready_hooks:
+        if self._on_ready is not None and self._on_ready in Fn.grad_ready_hooks:
             Fn.grad_ready_hooks.remove(self._on_ready)
+        self._on_ready = None
         self._early = None
 
+    def __del__(self):
+        try:
+            self.disable_early_all_reduce()
+        except Exception:           # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def _scale(self, world: int):
+        if self.defer_scale:
+            self.grad_scale = 1.0 / world           # folded into the fused optimizer step: no pass over the bucket
+        else:
+            self.flat.mul_(1.0 / world)
+
     def all_reduce(self, group=None, chunks: int = 1):
-        """sum over ranks then divide by world size (== DataParallel's global-batch mean)."""
+        """sum over ranks then divide by world size (== DataParallel's global-batch mean).  With a fused optimizer
+        attached (``defer_scale``) the division happens inside its step kernel."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
         if world == 1:
             return
-        work = getattr(self, '_early_work', None)
+        work = self._early_work
         if work is not None:                # the transformer's slice is already in flight (enable_early_all_reduce)
             lo = self._early[0]
             self._early_work = None
             if lo > 0:
                 dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM, group=group)
             work.wait()
-            self.flat.mul_(1.0 / world)
+            self._scale(world)
             return
         if chunks <= 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -126,7 +158,7 @@ class GradBucket:
                      for c in self.flat.chunk(chunks)]
             for w in works:
                 w.wait()
-        self.flat.mul_(1.0 / world)
+        self._scale(world)
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
@@ -135,6 +167,11 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src, group=group)
+    # `.data` has its own version counter: the cached bf16 / transposed operand copies of any weight that was already
+    # used in a forward would survive the overwrite.  (Anyone writing parameters through `.data` or raw pointers calls
+    # ops.invalidate_weight_cache() likewise.)
+    from . import ops
+    ops.invalidate_weight_cache()
 
 
 def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -146,19 +183,31 @@ def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return x[rank * per:(rank + 1) * per]
 
 
-class _FusedOptimizer:
+class _FusedOptimizer(torch.optim.Optimizer):
     """Common part of the fused optimizers: one HIP launch over GradBucket's flat parameter / gradient buffers
     (reference optimizers: train_CNN.py:196-201).  ``zero_grad=True`` makes the step kernel
-    write zeros over the gradients it has just consumed, so the training loop needs no zero-grad pass."""
+    write zeros over the gradients it has just consumed, so the training loop needs no zero-grad pass.
 
-    def __init__(self, bucket: GradBucket, zero_grad: bool):
+    They are torch.optim.Optimizer objects: ONE param group over the bucket's parameters whose hyper-parameters
+    (``lr`` ...) are read at every step, so ``lr_scheduler.CosineAnnealingLR(optimizer, ...)`` (train_CNN.py:202)
+    works; ``state_dict()`` / ``load_state_dict()`` carry the step count and the flat state buffers."""
+
+    _state_names: Tuple[str, ...] = ()
+
+    def __init__(self, bucket: GradBucket, defaults: dict, zero_grad: bool):
         if bucket.flat_params is None:
             raise ValueError('the fused optimizers need GradBucket(..., flatten_params=True)')
         if not bucket.flat.is_cuda:
             raise RuntimeError('the fused optimizers run on the GPU only (no CPU fallback)')
+        super().__init__(bucket.params, defaults)
         self.bucket = bucket
+        bucket.defer_scale = True           # all_reduce() leaves the sum; step() applies 1 / world size
         self.fused_zero_grad = bool(zero_grad)
         self.steps = 0
+
+    @property
+    def hyper(self) -> dict:
+        return self.param_groups[0]
 
     def zero_grad(self, set_to_none: bool = False):
         if set_to_none:
@@ -169,46 +218,64 @@ class _FusedOptimizer:
     def _done(self):
         from . import ops
         self.steps += 1
+        self.bucket.grad_scale = 1.0
         ops.invalidate_weight_cache()       # the kernel wrote parameters without bumping their version counters
+
+    def state_dict(self):
+        return {'steps': self.steps, 'param_groups': [{k: v for k, v in self.hyper.items() if k != 'params'}],
+                'flat_state': {n: getattr(self, n).detach().clone() for n in self._state_names}}
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd['steps'])
+        self.hyper.update(sd['param_groups'][0])
+        for n in self._state_names:
+            getattr(self, n).copy_(sd['flat_state'][n])
 
 
 class FusedSGD(_FusedOptimizer):
     """torch.optim.SGD(params, lr, momentum, dampening, weight_decay, nesterov) over the flat buffers."""
 
+    _state_names = ('momentum_buffer',)
+
     def __init__(self, bucket: GradBucket, lr: float, momentum: float = 0.0, dampening: float = 0.0,
                  weight_decay: float = 0.0, nesterov: bool = False, zero_grad: bool = False):
-        super().__init__(bucket, zero_grad)
         if nesterov and (momentum <= 0 or dampening != 0):
             raise ValueError('Nesterov momentum requires a momentum and zero dampening')
-        self.lr, self.momentum, self.dampening = float(lr), float(momentum), float(dampening)
-        self.weight_decay, self.nesterov = float(weight_decay), bool(nesterov)
+        super().__init__(bucket, dict(lr=float(lr), momentum=float(momentum), dampening=float(dampening),
+                                      weight_decay=float(weight_decay), nesterov=bool(nesterov)), zero_grad)
         self.momentum_buffer = torch.zeros_like(bucket.flat)
 
-    def step(self):
+    lr = property(lambda self: self.hyper['lr'])
+
+    @torch.no_grad()
+    def step(self, closure=None):
         from . import _lib, ops
-        b = self.bucket
+        b, h = self.bucket, self.hyper
         _lib.check(_lib.lib().istvt_sgd_momentum(b.flat_params.data_ptr(), b.flat.data_ptr(), self.momentum_buffer.data_ptr(),
-                                                 b.numel, self.lr, self.momentum, self.dampening, self.weight_decay,
-                                                 int(self.nesterov), int(self.steps == 0), int(self.fused_zero_grad),
-                                                 ops._stream()), 'istvt_sgd_momentum')
+                                                 b.numel, h['lr'], h['momentum'], h['dampening'], h['weight_decay'],
+                                                 int(h['nesterov']), int(self.steps == 0), int(self.fused_zero_grad),
+                                                 float(b.grad_scale), ops._stream()), 'istvt_sgd_momentum')
         self._done()
 
 
 class FusedAdamW(_FusedOptimizer):
     """torch.optim.AdamW(params, lr, betas, eps, weight_decay) (amsgrad off) over the flat buffers."""
 
+    _state_names = ('exp_avg', 'exp_avg_sq')
+
     def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, zero_grad: bool = False):
-        super().__init__(bucket, zero_grad)
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        super().__init__(bucket, dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                                      weight_decay=float(weight_decay)), zero_grad)
         self.exp_avg = torch.zeros_like(bucket.flat)
         self.exp_avg_sq = torch.zeros_like(bucket.flat)
 
-    def step(self):
+    @torch.no_grad()
+    def step(self, closure=None):
         from . import _lib, ops
-        b = self.bucket
+        b, h = self.bucket, self.hyper
         _lib.check(_lib.lib().istvt_adamw(b.flat_params.data_ptr(), b.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                          self.exp_avg_sq.data_ptr(), b.numel, self.lr, self.betas[0], self.betas[1],
-                                          self.eps, self.weight_decay, self.steps + 1, int(self.fused_zero_grad),
-                                          ops._stream()), 'istvt_adamw')
+                                          self.exp_avg_sq.data_ptr(), b.numel, h['lr'], h['betas'][0], h['betas'][1],
+                                          h['eps'], h['weight_decay'], self.steps + 1, int(self.fused_zero_grad),
+                                          float(b.grad_scale), ops._stream()), 'istvt_adamw')
         self._done()

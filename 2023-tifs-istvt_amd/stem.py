@@ -92,8 +92,9 @@ def bn_apply(u: Tensor, st: BNState, M: int, C: int, relu: bool) -> Tensor:
 
 
 def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: int, stats: Optional[Tensor] = None,
-                dg: Optional[Tensor] = None, db: Optional[Tensor] = None):
-    """-> (du, dgamma, dbeta).  `stats` = new_stats() buffer already accumulated (not yet reduced) by a
+                dg: Optional[Tensor] = None, db: Optional[Tensor] = None, training: bool = True):
+    """-> (du, dgamma, dbeta).  training=False: the pack holds running statistics (constants), so du = gamma*rstd*dz
+    while dgamma / dbeta keep their sums.  `stats` = new_stats() buffer already accumulated (not yet reduced) by a
     fused producer (the depthwise input-gradient kernel).  dg / db: float32 [C] buffers to accumulate into
     (a parameter's .grad); fresh zero tensors otherwise."""
     L = _lib.lib()
@@ -110,7 +111,7 @@ def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: in
         db = torch.zeros((C,), dtype=torch.float32, device=u.device)
     _lib.check(L.istvt_bn_bwd_apply(dz.data_ptr(), u.data_ptr(), st.ptr(), gamma.data_ptr(),
                                     stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), du.data_ptr(), dg.data_ptr(),
-                                    db.data_ptr(), M, C, dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
+                                    db.data_ptr(), M, C, int(training), dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
     return du, dg, db
 
 
@@ -285,8 +286,7 @@ class StemFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         sv = ctx.sv
-        if not sv['training']:
-            raise NotImplementedError('backward through the stem in eval() mode (running-stat BatchNorm) is not implemented')
+        training = sv['training']           # eval mode: every BatchNorm is an affine map with constant statistics
         L = _lib.lib()
         P, Fr, dtype = sv['P'], sv['Fr'], sv['dtype']
         dtc = ops._DT[dtype]
@@ -303,7 +303,7 @@ class StemFn(Function):
 
         def bn_bwd(dz, u, st, n, M, C, stats=None):
             tg, tb = tgt(n + '.weight', (C,)), tgt(n + '.bias', (C,))
-            du, dg, db = bn_backward(dz, u, st, P[n + '.weight'], M, C, stats=stats, dg=tg, db=tb)
+            du, dg, db = bn_backward(dz, u, st, P[n + '.weight'], M, C, stats=stats, dg=tg, db=tb, training=training)
             if tg is None:
                 grads[n + '.weight'] = dg
             if tb is None:

@@ -127,9 +127,13 @@ int istvt_bn_apply(const void* x, const float* bnp, void* y, long M, int C, int 
 /* s1 += sum dz, s2 += sum dz*xhat (double[C]);  du = gamma*rstd*(dz - s1/M - xhat*s2/M), dgamma += s2, dbeta += s1 */
 int istvt_bn_bwd_stats(const void* dz, const void* u, const float* bnp, double* s1, double* s2, long M, int C,
                        int dtype, istvt_stream_t stream);
+/* batch_stats = 0: eval-mode BatchNorm (running statistics are constants): du = gamma*rstd*dz */
 int istvt_bn_bwd_apply(const void* dz, const void* u, const float* bnp, const float* gamma, const double* s1,
-                       const double* s2, void* du, float* dgamma, float* dbeta, long M, int C, int dtype,
-                       istvt_stream_t stream);
+                       const double* s2, void* du, float* dgamma, float* dbeta, long M, int C, int batch_stats,
+                       int dtype, istvt_stream_t stream);
+/* tail of a stride-1 Block (xception.py:91-100 without the MaxPool): out = bn_x(x) + (bns ? bn_s(skip) : skip) */
+int istvt_bn_add_fwd(const void* x, const float* bnx, const void* skip, const float* bns, void* out, long M, int C,
+                     int dtype, istvt_stream_t stream);
 
 /* conv1 (3->32, 3x3, s2, p0; xception.py:118): NCHW float clip -> col[M][32] ((dy,dx,ci) + 5 zero cols); adjoint */
 int istvt_im2col_conv1(const float* x, void* col, int frames, int S, int dtype, istvt_stream_t stream);
@@ -166,7 +170,8 @@ int istvt_conv2_wgrad_slabs(void);
  * the weight gradient dw is float[C][9] (PyTorch order).
  * forward: in_bn (+in_relu) = the preceding BatchNorm+ReLU applied on load (xception.py:67,73).
  * input gradient (flip=1): epilogue = ReLU mask of msrc (optionally through m_bn) before (mask_pre) /
- * after (mask_post) adding the stride-2 skip-path gradient addsrc[f][y/2][x/2], plus fused
+ * after (mask_post) adding the stride-2 skip-path gradient addsrc[f][y/2][x/2] (Ha = (H-1)/2+1, Wa likewise) or, for
+ * the stride-1 blocks, the full-resolution one addsrc[f][y][x] (Ha = H, Wa = W), plus fused
  * BatchNorm-backward sums st_s1/st_s2 (double[C]) of the result w.r.t. m_bn. */
 int istvt_dwconv3x3(const void* in, const float* w, void* out, int frames, int H, int W, int C, const float* in_bn,
                     int in_relu, int flip, const void* msrc, const float* m_bn, int mask_pre, int mask_post,
@@ -182,6 +187,32 @@ int istvt_pool_bwd(const void* dout, const unsigned char* argmax, void* dz, int 
                    int dtype, istvt_stream_t stream);
 /* input of the stride-2 1x1 skip conv (xception.py:57): out[f][y][x] = in[f][2y][2x] */
 int istvt_subsample2(const void* in, void* out, int frames, int H, int W, int C, int dtype, istvt_stream_t stream);
+
+/* ==== next rows: Xception exit flow head, ablation transformers, dropout ==== */
+/* Xception.logits (xception.py:208-213): out[f][c] = mean_hw relu(x[f][hw][c]) on NHWC features; relu = 0: plain mean */
+int istvt_relu_avgpool_fwd(const void* x, void* out, int frames, int HW, int C, int relu, int dtype,
+                           istvt_stream_t stream);
+int istvt_relu_avgpool_bwd(const void* x, const void* dout, void* dx, int frames, int HW, int C, int relu, int dtype,
+                           istvt_stream_t stream);
+/* Token assembly of ViViT / VanillaTr (vivit.py:60-67,74-75,180-186): S sequences of n rows -> n + 1 rows,
+ * out[s][0] = tok (+ pos[s % period][0]), out[s][1+i] = src[s][i] (+ pos[s % period][1+i]); pos float
+ * [period][pos_rows][D] or NULL.  bwd: dsrc (may be NULL), dtok / dpos accumulate (float). */
+int istvt_prepend_fwd(const void* src, const float* tok, const float* pos, void* out, long ldo, long S, int n, int D,
+                      int period, int pos_rows, int dtype, istvt_stream_t stream);
+int istvt_prepend_bwd(const void* dout, long ldd, void* dsrc, float* dtok, float* dpos, long S, int n, int D,
+                      int period, int pos_rows, int dtype, istvt_stream_t stream);
+/* x.mean(dim=1) of [S][n][D] (ViViT pool='mean', vivit.py:79) and its adjoint */
+int istvt_seq_mean_fwd(const void* x, long ldx, void* out, long S, int n, int D, int dtype, istvt_stream_t stream);
+int istvt_seq_mean_bwd(const void* dout, void* dx, long ldx, long S, int n, int D, int dtype, istvt_stream_t stream);
+/* nn.Dropout(p) in training mode (module.py:29,31,78,187; models_copy.py:41-44): Philox4x32-10 keyed by `seed`,
+ * mask = one byte per element (1 = kept), y = mask ? x / (1 - p) : 0; backward applies the stored mask. */
+int istvt_dropout_fwd(const void* x, long ldx, void* y, long ldy, unsigned char* mask, long M, int D, float p,
+                      unsigned long long seed, int dtype, istvt_stream_t stream);
+int istvt_dropout_bwd(const void* dy, long ldy, const unsigned char* mask, void* dx, long ldx, long M, int D, float p,
+                      int dtype, istvt_stream_t stream);
+/* out = a + b on row-strided [M][D] views: the residual add behind an active Dropout (module.py:78,187 with p > 0) */
+int istvt_add(const void* a, long lda, const void* b, long ldb, void* out, long ldo, long M, int D, int dtype,
+              istvt_stream_t stream);
 
 /* ---- helpers -------------------------------------------------------------------------------- */
 /* out[n] += sum_m x[m][n]  (bias gradients) */
@@ -199,11 +230,14 @@ int istvt_cast_transpose(const float* in, long ldi, void* out, long ldo, void* o
  * p, g, state: n floats each, 16-byte aligned (parallel.GradBucket(flatten_params=True)).  Semantics are torch.optim's:
  * sgd: g' = g + wd p; buf = first_step ? g' : momentum buf + (1 - dampening) g'; p -= lr (nesterov ? g' + momentum buf : buf)
  * adamw (amsgrad off): p *= 1 - lr wd; m, v moments; p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
- * zero_grad != 0 also writes zeros over g (the next step's zero-grad pass). */
+ * zero_grad != 0 also writes zeros over g (the next step's zero-grad pass).  grad_scale multiplies g on load: the
+ * 1 / world_size of the data-parallel gradient mean (the all-reduce then only sums; no separate scaling pass).
+ * momentum == 0 ignores dampening, as torch does. */
 int istvt_sgd_momentum(float* p, float* g, float* buf, long n, float lr, float momentum, float dampening,
-                       float weight_decay, int nesterov, int first_step, int zero_grad, istvt_stream_t stream);
+                       float weight_decay, int nesterov, int first_step, int zero_grad, float grad_scale,
+                       istvt_stream_t stream);
 int istvt_adamw(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                float weight_decay, long step, int zero_grad, istvt_stream_t stream);
+                float weight_decay, long step, int zero_grad, float grad_scale, istvt_stream_t stream);
 
 #ifdef __cplusplus
 }

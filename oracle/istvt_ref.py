@@ -292,3 +292,162 @@ def random_params(shapes: Dict[str, tuple], seed: int = 0, dtype=torch.float32) 
 def with_grad(p: Params) -> Params:
     return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
             for k, v in p.items()}
+
+
+# ----------------------------------------------------------------------------------
+# Round 2 -- SURVEY 8(f) rows 3 and 4: the whole Xception (middle + exit flow) and the
+# ablation attention variants.  Pinned by goldens G7 / G8 (tests/test_oracle_golden.py).
+# ----------------------------------------------------------------------------------
+def block_units(cin: int, cout: int, reps: int, grow_first: bool):
+    """(in, out) channels of the separable convolutions of Block(cin, cout, reps, ...) in execution order
+    (xception.py:64-80)."""
+    units = []
+    filters = cin
+    if grow_first:
+        units.append((cin, cout))
+        filters = cout
+    units += [(filters, filters)] * (reps - 1)
+    if not grow_first:
+        units.append((cin, cout))
+    return units
+
+
+def block_forward(p: Params, name: str, inp: Tensor, cin: int, cout: int, reps: int, strides: int = 1,
+                  start_with_relu: bool = True, grow_first: bool = True, training: bool = True) -> Tensor:
+    """Block.forward for any constructor arguments (xception.py:52-101).  rep is [ReLU, Sep, BN] per unit with the
+    leading ReLU dropped (start_with_relu=False) or made non-inplace (the skip branch sees the raw input either way),
+    MaxPool2d(3, strides, 1) appended when strides != 1; skip = BN(Conv1x1(stride)) when the shape changes, identity
+    otherwise.  `name` may be '' for a bare Block's own state dict."""
+    pre = name + '.' if name else ''
+    units = block_units(cin, cout, reps, grow_first)
+    idx = 0 if not start_with_relu else 1           # position of the first SeparableConv2d inside rep
+    x = inp
+    for i, _ in enumerate(units):
+        if i > 0 or start_with_relu:
+            x = F.relu(x)
+        x = _sepconv(p, '%srep.%d' % (pre, idx), x)
+        x = _bn(p, '%srep.%d' % (pre, idx + 1), x, training)
+        idx += 3
+    if strides != 1:
+        x = F.max_pool2d(x, 3, strides, 1)
+    if (pre + 'skip.weight') in p:
+        skip = F.conv2d(inp, p[pre + 'skip.weight'], None, strides)
+        skip = _bn(p, pre + 'skipbn', skip, training)
+    else:
+        skip = inp
+    return x + skip
+
+
+XCEPTION_BLOCKS = ([('block1', 64, 128, 2, 2, False, True), ('block2', 128, 256, 2, 2, True, True),
+                    ('block3', 256, 728, 2, 2, True, True)]
+                   + [('block%d' % i, 728, 728, 3, 1, True, True) for i in range(4, 12)]
+                   + [('block12', 728, 1024, 2, 2, True, False)])
+
+
+def xception_features(p: Params, x: Tensor, training: bool = True) -> Tensor:
+    """Xception.features (xception.py:161-191): entry, middle and exit flow up to bn4 (no final ReLU)."""
+    x = F.relu(_bn(p, 'bn1', F.conv2d(x, p['conv1.weight'], None, 2, 0), training))
+    x = F.relu(_bn(p, 'bn2', F.conv2d(x, p['conv2.weight']), training))
+    for name, cin, cout, reps, strides, relu0, grow in XCEPTION_BLOCKS:
+        x = block_forward(p, name, x, cin, cout, reps, strides, relu0, grow, training)
+    x = F.relu(_bn(p, 'bn3', _sepconv(p, 'conv3', x), training))
+    return _bn(p, 'bn4', _sepconv(p, 'conv4', x), training)
+
+
+def xception_logits(p: Params, feats: Tensor, head: str = 'last_linear') -> Tensor:
+    """Xception.logits (xception.py:208-215): ReLU, global average pool, last_linear."""
+    x = F.adaptive_avg_pool2d(F.relu(feats), (1, 1)).flatten(1)
+    return F.linear(x, p[head + '.weight'], p[head + '.bias'])
+
+
+def xception_param_shapes(num_classes: int = 1000) -> Dict[str, tuple]:
+    s: Dict[str, tuple] = {}
+
+    def bn(name, c):
+        s[name + '.weight'] = (c,); s[name + '.bias'] = (c,)
+        s[name + '.running_mean'] = (c,); s[name + '.running_var'] = (c,); s[name + '.num_batches_tracked'] = ()
+
+    s['conv1.weight'] = (32, 3, 3, 3); bn('bn1', 32)
+    s['conv2.weight'] = (64, 32, 3, 3); bn('bn2', 64)
+    for name, cin, cout, reps, strides, relu0, grow in XCEPTION_BLOCKS:
+        s.update({name + '.' + k: v for k, v in block_param_shapes(cin, cout, reps, strides, relu0, grow).items()})
+    s['conv3.conv1.weight'] = (1024, 1, 3, 3); s['conv3.pointwise.weight'] = (1536, 1024, 1, 1); bn('bn3', 1536)
+    s['conv4.conv1.weight'] = (1536, 1, 3, 3); s['conv4.pointwise.weight'] = (2048, 1536, 1, 1); bn('bn4', 2048)
+    s['last_linear.weight'] = (num_classes, 2048); s['last_linear.bias'] = (num_classes,)
+    return s
+
+
+def block_param_shapes(cin: int, cout: int, reps: int, strides: int, start_with_relu: bool, grow_first: bool):
+    s: Dict[str, tuple] = {}
+
+    def bn(name, c):
+        s[name + '.weight'] = (c,); s[name + '.bias'] = (c,)
+        s[name + '.running_mean'] = (c,); s[name + '.running_var'] = (c,); s[name + '.num_batches_tracked'] = ()
+
+    if cout != cin or strides != 1:
+        s['skip.weight'] = (cout, cin, 1, 1)
+        bn('skipbn', cout)
+    idx = 0 if not start_with_relu else 1
+    for a, b in block_units(cin, cout, reps, grow_first):
+        s['rep.%d.conv1.weight' % idx] = (a, 1, 3, 3)
+        s['rep.%d.pointwise.weight' % idx] = (b, a, 1, 1)
+        bn('rep.%d' % (idx + 1), b)
+        idx += 3
+    return s
+
+
+# ---- ablation attention variants (module.py:36-64, 145-172; vivit.py:10-25, 29-81, 150-191) ----
+def attention(p: Params, name: str, x: Tensor, heads: int) -> Tensor:
+    """Attention.forward (module.py:52-64): plain multi-head self-attention over all n tokens of a sequence."""
+    b, n, _ = x.shape
+    q, k, v = (t.view(b, n, heads, -1).transpose(1, 2) for t in F.linear(x, p[name + '.to_qkv.weight']).chunk(3, dim=-1))
+    dots = torch.matmul(q, k.transpose(-1, -2)) * q.shape[-1] ** -0.5
+    out = torch.matmul(dots.softmax(dim=-1), v).transpose(1, 2).reshape(b, n, -1)
+    return F.linear(out, p[name + '.to_out.0.weight'], p[name + '.to_out.0.bias'])
+
+
+def temporal_only_attention(p: Params, name: str, x: Tensor, hw: int, heads: int) -> Tensor:
+    """TemporalOnlyAttention.forward (module.py:161-172): one packed to_qkv, attention over the frame axis per
+    (batch, head, position); no frame difference."""
+    b, n, _ = x.shape
+    frames = n // hw
+    q, k, v = (_heads_split(t, b, frames, hw, heads).transpose(2, 3)
+               for t in F.linear(x, p[name + '.to_qkv.weight']).chunk(3, dim=-1))          # b h hw t d
+    dots = torch.matmul(q, k.transpose(-1, -2)) * q.shape[-1] ** -0.5
+    out = torch.matmul(dots.softmax(dim=-1), v).permute(0, 3, 2, 1, 4).reshape(b, n, -1)
+    return F.linear(out, p[name + '.to_out.0.weight'], p[name + '.to_out.0.bias'])
+
+
+def transformer(p: Params, name: str, x: Tensor, depth: int, heads: int) -> Tensor:
+    """Transformer.forward (vivit.py:21-25): x = attn(LN(x)) + x ; x = ff(LN(x)) + x ; final LayerNorm."""
+    for i in range(depth):
+        lp = '%s.layers.%d' % (name, i)
+        x = attention(p, lp + '.0.fn', layer_norm(p, lp + '.0.norm', x), heads) + x
+        x = feed_forward(p, lp + '.1.fn', layer_norm(p, lp + '.1.norm', x)) + x
+    return layer_norm(p, name + '.norm', x)
+
+
+def vivit_forward(p: Params, feats: Tensor, depth: int, heads: int, pool: str = 'cls') -> Tensor:
+    """ViViT.forward (vivit.py:60-81): per-frame space transformer on [space_token | patches] + pos, its cls rows
+    -> [temporal_token | frames] -> temporal transformer -> cls (or mean) -> mlp_head."""
+    b, t, c, h, w = feats.shape
+    x = feats.flatten(3).transpose(2, 3)                                      # b t (h w) c
+    n = x.shape[2]
+    x = torch.cat((p['space_token'].view(1, 1, 1, c).expand(b, t, 1, c), x), dim=2) + p['pos_embedding'][:, :, :n + 1]
+    x = transformer(p, 'space_transformer', x.reshape(b * t, n + 1, c), depth, heads)
+    x = x[:, 0].view(b, t, c)
+    x = torch.cat((p['temporal_token'].view(1, 1, c).expand(b, 1, c), x), dim=1)
+    x = transformer(p, 'temporal_transformer', x, depth, heads)
+    x = x.mean(dim=1) if pool == 'mean' else x[:, 0]
+    return F.linear(layer_norm(p, 'mlp_head.0', x), p['mlp_head.1.weight'], p['mlp_head.1.bias'])
+
+
+def vanilla_tr_forward(p: Params, feats: Tensor, depth: int, heads: int) -> Tensor:
+    """VanillaTr.forward (vivit.py:180-191): Linear patch embedding of every (frame, position), one cls token, one
+    joint transformer over all t*h*w + 1 tokens."""
+    b, t, c, h, w = feats.shape
+    x = F.linear(feats.flatten(3).transpose(2, 3), p['to_patch_embedding.1.weight'], p['to_patch_embedding.1.bias'])
+    x = x.reshape(b, t * h * w, -1)
+    x = torch.cat((p['cls_token'].expand(b, 1, -1), x), dim=1) + p['pos_embedding']
+    x = transformer(p, 'transformer', x, depth, heads)[:, 0]
+    return F.linear(layer_norm(p, 'mlp_head.0', x), p['mlp_head.1.weight'], p['mlp_head.1.bias'])

@@ -246,6 +246,211 @@ def g0_state_dict():
 
 ALL = {'G0': g0_state_dict, 'G1': g1_stem, 'G2': g2_modules, 'G3': g3_layer, 'G4': g4_dsttr, 'G5': g5_end_to_end, 'G6': g6_fullwidth}
 
+
+# --------------------------------------------------------------------------------------
+# round 2: the fixtures SURVEY 8(c) lists that round 1 skipped, float64 references, Xception blocks / full network,
+# the sibling attention variants.  New files only: G1-G6 above stay byte-identical.
+# --------------------------------------------------------------------------------------
+def g1b_stem224():
+    """G1 at 224^2 (xception.py:193-206 at the benchmark geometry: 14x14 output)."""
+    out = {}
+    side = 224
+    net = ref_xception.xception(pretrained=False)
+    load_recipe(net, 'xcep.model.')
+    net.train()
+    x = t(recipe.input_value('g1.x%d' % side, (2, 3, side, side))).requires_grad_(True)
+    y = net.low_level_features(x)
+    coef = t(recipe.input_value('g1.coef%d' % side, tuple(y.shape)))
+    (y * coef).sum().backward()
+    tag = 's%d.' % side
+    out[tag + 'y'] = npy(y)
+    out[tag + 'dx_norm'] = npy(x.grad.norm())
+    out[tag + 'dx_slice'] = npy(x.grad[0, :, 10:14, 20:28])
+    sd = net.state_dict()
+    for k in ('bn1', 'bn2', 'block1.skipbn', 'block2.rep.2', 'block3.rep.5', 'block3.skipbn'):
+        out[tag + k + '.running_mean'] = npy(sd[k + '.running_mean'])
+        out[tag + k + '.running_var'] = npy(sd[k + '.running_var'])
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+    for k in ('conv1.weight', 'block2.rep.4.conv1.weight', 'block3.skip.weight'):
+        out[tag + 'grad.' + k] = npy(dict(net.named_parameters())[k].grad.reshape(-1)[:4096])
+    save('G1b_stem224', **out)
+
+
+def g2b_modules_f17():
+    """G2 at F = 17 frames (T = 16: the C4 temporal tile; module.py:174-208 with 17 keys per softmax)."""
+    out = {}
+    dim, heads, dh = MOD_CFG['dim'], MOD_CFG['heads'], MOD_CFG['dim_head']
+    F, st = 17, 13
+    shape = (1, F * 362, dim)
+    mods = {
+        'prenorm_ff': ref_module.PreNorm(dim, ref_module.FeedForward(dim, 4 * dim)),
+        'spatial': ref_module.SpatialOnlyAttention(dim, heads=heads, dim_head=dh),
+        'temporal': ref_module.TemporalResidualAttention(dim, heads=heads, dim_head=dh),
+    }
+    for name, mod in mods.items():
+        load_recipe(mod, 'g2.%s.' % name)
+        res = _run_module(mod, 'g2.%s.F%d' % (name, F), shape)
+        for k, v in res.items():
+            if k in ('y', 'dx'):
+                v = v[:, ::st]
+            out['F%d.%s.%s' % (F, name, k)] = v
+    save('G2b_modules_F17', **out)
+
+
+def g4b_dsttr_t16():
+    out = {}
+    dim, heads, dh = MOD_CFG['dim'], MOD_CFG['heads'], MOD_CFG['dim_head']
+    T = 16
+    mod = ref_vivit.DSTTr(19, 1, 1, T, dim=dim, depth=2, heads=heads, dim_head=dh, in_channels=dim, scale_dim=2)
+    load_recipe(mod, 'g4.')
+    x = t(recipe.input_value('g4.x.T%d' % T, (2, T, dim, 19, 19))).requires_grad_(True)
+    y = mod(x)
+    coef = t(recipe.input_value('g4.coef', tuple(y.shape)))
+    (y * coef).sum().backward()
+    tag = 'T%d.' % T
+    out[tag + 'logits'] = npy(y)
+    out[tag + 'dx_norm'] = npy(x.grad.norm())
+    out[tag + 'dx_frame_norms'] = npy(x.grad.flatten(2).norm(dim=2))
+    for k, p in mod.named_parameters():
+        out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+    out[tag + 'grad.pos_embedding'] = npy(mod.pos_embedding.grad[0, :, ::37])
+    out[tag + 'grad.space_token'] = npy(mod.space_token.grad)
+    out[tag + 'grad.temporal_token'] = npy(mod.temporal_token.grad)
+    save('G4b_dsttr_T16', **out)
+
+
+def g5b_native_fp64():
+    """G5 again with the reference run in float64 (same float32-valued recipe weights / input, exactly representable):
+    the yardstick for "HIP error <= k x the reference's own float32 error" per gradient tensor."""
+    model = ref_vivit.XceptionVidTr()
+    load_recipe(model, '')
+    model = model.double().train()
+    x = t(recipe.input_value('g5.x', (1, 6, 3, 300, 300))).double()
+    labels = torch.ones(1, dtype=torch.float64)
+    logits = model(x)
+    loss = nn.BCEWithLogitsLoss()(logits.view(-1), labels)
+    loss.backward()
+    out = {'logits64': npy(logits), 'loss64': npy(loss)}
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            out['gnorm64.' + k] = npy(p.grad.norm())
+    named = dict(model.named_parameters())
+    for k in ['vit.transformer.layers.0.0.fn.to_qk.weight', 'vit.transformer.layers.11.2.fn.net.3.weight',
+              'vit.transformer.layers.5.1.fn.to_qkv.weight', 'vit.pos_embedding', 'xcep.model.conv1.weight',
+              'xcep.model.block3.rep.4.pointwise.weight']:
+        out['grad64.' + k] = npy(named[k].grad.reshape(-1)[:64])
+    save('G5b_native_fp64', **out)
+
+
+def load_rand(module: nn.Module, prefix: str = ''):
+    sd = module.state_dict()
+    vals = recipe.rand_fill_state_dict(sd, prefix)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+
+
+def _block_case(out, tag, mod, prefix, shape, dtype=torch.float32):
+    load_rand(mod, prefix)
+    mod = mod.to(dtype).train()
+    x = t(recipe.rand_input_value(prefix + 'x', shape)).to(dtype).requires_grad_(True)
+    y = mod(x)
+    coef = t(recipe.rand_input_value(prefix + 'coef', tuple(y.shape))).to(dtype)
+    (y * coef).sum().backward()
+    f64 = dtype == torch.float64
+    out[tag + 'y'] = npy(y)
+    out[tag + 'dx_norm'] = npy(x.grad.norm())
+    if not f64:
+        out[tag + 'dx'] = npy(x.grad)
+    for k, p in mod.named_parameters():
+        out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+        if not f64:
+            out[tag + 'grad.' + k] = npy(p.grad.reshape(-1)[:4096])      # whole tensor when it is that small
+    for k, v in mod.state_dict().items():
+        if 'running' in k and not f64:
+            out[tag + 'buf.' + k] = npy(v)
+
+
+def g7_xception():
+    """Block / SeparableConv2d by themselves (xception.py:46-49, 91-101), then the whole network: features(), logits(),
+    forward() (xception.py:161-215) at 299^2, train mode, batch 2.  Pseudo-random recipe (recipe.rand_*)."""
+    out = {}
+    B = ref_xception.Block
+    cases = [('b1', lambda: B(64, 128, 2, 2, start_with_relu=False, grow_first=True), (2, 64, 21, 21)),
+             ('b2', lambda: B(128, 256, 2, 2, start_with_relu=True, grow_first=True), (2, 128, 15, 15)),
+             ('b4', lambda: B(728, 728, 3, 1, start_with_relu=True, grow_first=True), (2, 728, 10, 10)),
+             ('b12', lambda: B(728, 1024, 2, 2, start_with_relu=True, grow_first=False), (2, 728, 10, 10)),
+             ('sep', lambda: ref_xception.SeparableConv2d(64, 128, 3, 1, 1), (2, 64, 13, 17))]
+    for name, ctor, shape in cases:
+        _block_case(out, name + '.', ctor(), 'g7.%s.' % name, shape)
+        _block_case(out, name + '.f64.', ctor(), 'g7.%s.' % name, shape, torch.float64)
+    # the whole network
+    for dtype, tag in ((torch.float32, 'net.'), (torch.float64, 'net.f64.')):
+        net = ref_xception.xception(pretrained=False)
+        load_rand(net, 'g7.net.')
+        net = net.to(dtype).train()
+        x = t(recipe.rand_input_value('g7.net.x', (2, 3, 299, 299))).to(dtype).requires_grad_(True)
+        feats = net.features(x)
+        out[tag + 'features_sub'] = npy(feats[:, ::16]).copy()   # every 16th channel of (2, 2048, 10, 10), pre-ReLU (a copy: logits() rectifies feats in place)
+        logits = net.logits(feats)                                # NB: relu is in place on feats (xception.py:209)
+        coef = t(recipe.rand_input_value('g7.net.coef', tuple(logits.shape))).to(dtype)
+        (logits * coef).sum().backward()
+        out[tag + 'logits'] = npy(logits)
+        out[tag + 'dx_norm'] = npy(x.grad.norm())
+        for k, p in net.named_parameters():
+            out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+        sd = net.state_dict()
+        for k in ('bn1', 'block5.rep.2', 'block12.skipbn', 'bn3', 'bn4'):
+            out[tag + 'buf.' + k + '.running_mean'] = npy(sd[k + '.running_mean'])
+            out[tag + 'buf.' + k + '.running_var'] = npy(sd[k + '.running_var'])
+    # eval-mode forward (running statistics as updated by the one training step above would differ per dtype: use fresh)
+    net = ref_xception.xception(pretrained=False)
+    load_rand(net, 'g7.net.')
+    net.eval()
+    with torch.no_grad():
+        out['net.eval.logits'] = npy(net(t(recipe.rand_input_value('g7.net.x', (2, 3, 299, 299)))))
+    save('G7_xception', **out)
+
+
+def g8_siblings():
+    """The ablation attention variants (module.py:36-64 Attention, :145-172 TemporalOnlyAttention; vivit.py:10-25
+    Transformer, :29-81 ViViT, :150-191 VanillaTr), small widths, pseudo-random recipe, float32 + float64."""
+    out = {}
+    dim, heads, dh = 64, 2, 32
+    cases = [('attention', lambda: ref_module.Attention(dim, heads=heads, dim_head=dh), (2, 50, dim)),
+             ('temporal_only', lambda: ref_module.TemporalOnlyAttention(dim, heads=heads, dim_head=dh), (1, 5 * 362, dim)),
+             ('transformer', lambda: ref_vivit.Transformer(dim, 2, heads, dh, 2 * dim), (2, 50, dim)),
+             ('vivit', lambda: ref_vivit.ViViT(19, 1, 3, 4, dim=dim, depth=1, heads=heads, dim_head=dh, in_channels=dim,
+                                               scale_dim=2), (2, 4, dim, 19, 19)),
+             ('vivit_mean', lambda: ref_vivit.ViViT(19, 1, 3, 4, dim=dim, depth=1, heads=heads, dim_head=dh, pool='mean',
+                                                    in_channels=dim, scale_dim=2), (2, 4, dim, 19, 19)),
+             ('vanilla', lambda: ref_vivit.VanillaTr(7, 1, 3, 4, dim=dim, depth=1, heads=heads, dim_head=dh,
+                                                     in_channels=dim, scale_dim=2), (2, 4, dim, 7, 7))]
+    for name, ctor, shape in cases:
+        for dtype, tag in ((torch.float32, name + '.'), (torch.float64, name + '.f64.')):
+            mod = ctor()
+            load_rand(mod, 'g8.%s.' % name)
+            mod = mod.to(dtype).train()
+            x = t(recipe.rand_input_value('g8.%s.x' % name, shape)).to(dtype).requires_grad_(True)
+            y = mod(x)
+            coef = t(recipe.rand_input_value('g8.%s.coef' % name, tuple(y.shape))).to(dtype)
+            (y * coef).sum().backward()
+            big = y.numel() > 20000
+            f64 = dtype == torch.float64
+            out[tag + 'y'] = npy(y)[:, ::7] if big else npy(y)
+            if not f64:
+                out[tag + 'dx'] = npy(x.grad)[:, ::7] if (big or x.grad.numel() > 200000) else npy(x.grad)
+            out[tag + 'dx_norm'] = npy(x.grad.norm())
+            for k, p in mod.named_parameters():
+                out[tag + 'gnorm.' + k] = npy(p.grad.norm())
+                if not f64:
+                    out[tag + 'grad.' + k] = npy(p.grad.reshape(-1)[:4096])
+    save('G8_siblings', **out)
+
+
+ALL.update({'G1b': g1b_stem224, 'G2b': g2b_modules_f17, 'G4b': g4b_dsttr_t16, 'G5b': g5b_native_fp64, 'G7': g7_xception,
+            'G8': g8_siblings})
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')

@@ -53,3 +53,36 @@ def fill_state_dict(sd: dict, prefix: str = '') -> dict:
 
 def input_value(name: str, shape, scale: float = 1.0) -> np.ndarray:
     return wave('input:' + name, tuple(shape), scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# Pseudo-random recipe (round 2): the sin-wave weights above make a deep BatchNorm chain amplify fp32 noise ~2x per
+# layer (fine for the 6-layer entry flow, hopeless for the 40-layer full Xception), so the goldens of deep stacks use
+# default-init-like uniform weights from numpy's PCG64 (integer arithmetic: identical on every machine with this numpy).
+def _rng(name: str):
+    return np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+
+
+def rand_param_value(name: str, shape) -> np.ndarray:
+    shape = tuple(shape)
+    leaf = name.split('.')[-1]
+    if leaf in ('num_batches_tracked', 'running_mean', 'running_var'):
+        return param_value(name, shape)
+    g = _rng('param:' + name)
+    if leaf == 'weight' and len(shape) == 1:           # BatchNorm / LayerNorm gain
+        return (1.0 + 0.1 * g.uniform(-1.0, 1.0, shape)).astype(np.float32)
+    if leaf == 'bias':
+        return (0.1 * g.uniform(-1.0, 1.0, shape)).astype(np.float32)
+    if leaf in ('pos_embedding', 'space_token', 'temporal_token', 'cls_token'):
+        return g.standard_normal(shape).astype(np.float32)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+    b = np.sqrt(3.0 / max(fan_in, 1))                  # unit-gain uniform: activations stay O(1) through ReLU + BN
+    return g.uniform(-b, b, shape).astype(np.float32)
+
+
+def rand_fill_state_dict(sd: dict, prefix: str = '') -> dict:
+    return {k: rand_param_value(prefix + k, tuple(v.shape)) for k, v in sd.items()}
+
+
+def rand_input_value(name: str, shape, scale: float = 1.0) -> np.ndarray:
+    return (scale * _rng('input:' + name).standard_normal(tuple(shape))).astype(np.float32)

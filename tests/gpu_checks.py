@@ -635,3 +635,147 @@ def all_checks():  # noqa: F811
         out.append(('stem_convdense_%s' % tag, lambda dt=dt: conv_dense_check(dt)))
         out.append(('stem_convdense_odd_%s' % tag, lambda dt=dt: conv_dense_check(dt, 3, 77)))
     return out
+
+
+# ------------------------------------------------------------------------------------------ production shapes (round 2)
+# What bench.py runs and round 1 never parity-tested: the persistent 256x256 GEMM with MORE tiles than workgroups (several
+# tiles per workgroup: cross-tile LDS ring carry, p_setup advancing to the next tile, balanced rounds, XCD remap --
+# gemm256q.h:88-166, gemm.hip dispatch), 12 / 46 K tiles, padded rows; gemm256t with its split-K slabs at M = 56 736; the
+# attention grids at BF = 2 304 / B*P*h = 50 432.  References are computed ON THE CPU in float64 for sampled rows /
+# problems (rows of a GEMM and attention problems are independent, so a sample is an exact check of what it covers).
+M_C2 = 56736                      # B=32 x F=9 x P=197
+
+
+def _sample_rows(M, n, seed=0, tile=256):
+    """>= n row indices: the first and last rows of every row tile plus random ones"""
+    g = torch.Generator().manual_seed(seed)
+    edges = torch.arange(0, M, tile)
+    idx = torch.cat((edges, (edges + tile - 1).clamp_max(M - 1), torch.tensor([M - 1, M - 2, 223, 224, 447, 448]),
+                     torch.randint(0, M, (n,), generator=g)))
+    return torch.unique(idx)
+
+
+def gemm_production(mode, N, K, M=M_C2, nsample=2048):
+    """bf16, integer-valued operands, line-padded rows (NaN pad columns): exact against float64 on the CPU."""
+    dt = torch.bfloat16
+    idx = _sample_rows(M, nsample, seed=N + K)
+    ic = idx.cuda()
+    cpu = lambda t: t.detach().double().cpu()  # noqa: E731
+    if mode in ('fwd', 'fwd_bias_res', 'fwd_gelu'):
+        x, w = padded(ints((M, K), dt, 1)), padded(ints((N, K), dt, 2))
+        b = ints((N,), torch.float32, 4) if mode != 'fwd' else None
+        ref = cpu(x[ic]) @ cpu(w).t()
+        if mode == 'fwd_gelu':
+            u, g_ = ops.linear_fwd(x, w, b, gelu=True, pad=True)
+            ref = ref + cpu(b)
+            e = float((cpu(u[ic]) - ref.to(dt).double()).abs().max())                 # pre-activation: exact
+            rg = torch.nn.functional.gelu(ref.to(dt).double())                       # gelu of the STORED pre-activation
+            eg = float((cpu(g_[ic]) - rg).abs().max() / rg.abs().max())
+            assert u.stride(0) == ops.pad_ld(N)
+            return max(e, 0.0 if eg < 1e-2 else eg), 0.0
+        r = padded(ints((M, N), dt, 3)) if mode == 'fwd_bias_res' else None
+        y = ops.linear_fwd(x, w, b, r, pad=True)
+        if mode == 'fwd_bias_res':
+            ref = ref + cpu(b) + cpu(r[ic])
+        return float((cpu(y[ic]) - ref.to(dt).double()).abs().max()), 0.0
+    if mode in ('dgrad', 'dgrad_gelu'):
+        # dx [M, K] = dy [M, N] @ w [N, K]  (runs as an NT GEMM over the cached, row-padded W^T)
+        dy, w = padded(ints((M, N), dt, 5, -1, 2)), ints((N, K), dt, 6)
+        if mode == 'dgrad':
+            dx = ops.linear_dgrad(dy, w, pad=True)
+            ref = (cpu(dy[ic]) @ cpu(w)).to(dt).double()
+            return float((cpu(dx[ic]) - ref).abs().max()), 0.0
+        u = ops.empty_rows(M, K, dt, DEV)
+        u.copy_(rnd((M, K), dt, 7))
+        dx = ops.linear_dgrad(dy, w, gelu_u=u, pad=True)
+        ud = cpu(u[ic]).requires_grad_(True)
+        torch.nn.functional.gelu(ud).backward(cpu(dy[ic]) @ cpu(w))
+        return relerr(cpu(dx[ic]), ud.grad), TOL[dt]
+    # wgrad: dw [N, K] = dy^T x over all M rows; sampled output rows n
+    dy, x = padded(ints((M, N), dt, 8, -1, 2)), padded(ints((M, K), dt, 9))
+    dw = ops.linear_wgrad(dy, x)
+    ncols = torch.unique(torch.cat((torch.tensor([0, 1, 255, 256, N - 1]), torch.randint(0, N, (59,), generator=torch.Generator().manual_seed(3)))))
+    ref = cpu(dy[:, ncols.cuda()]).t() @ cpu(x)
+    return float((cpu(dw[ncols.cuda()]) - ref).abs().max()), 0.0
+
+
+def attn_spatial_production(BF=2304, P=197, heads=8, dh=64, nsample=40):
+    """the full C2 attention grid (2 304 frames x 8 heads); forward and backward of sampled (frame, head) problems
+    against float64 attention of the same bf16 inputs on the CPU."""
+    dt = torch.bfloat16
+    inner = heads * dh
+    g = torch.Generator(device='cuda').manual_seed(1)
+    qkv = torch.randn((BF * P, 3 * inner), generator=g, device=DEV, dtype=torch.float32).to(dt)
+    dout = torch.randn((BF * P, inner), generator=g, device=DEV, dtype=torch.float32).to(dt)
+    out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh)
+    dqkv = ops.attn_spatial_bwd(qkv, out, dout, lse, BF, P, heads, dh)
+    gs = torch.Generator().manual_seed(2)
+    frames = torch.unique(torch.cat((torch.tensor([0, 1, BF - 1, BF // 2]), torch.randint(0, BF, (nsample,), generator=gs))))
+    worst = 0.0
+    for i, f in enumerate(frames.tolist()):
+        h = i % heads
+        rows = slice(f * P, (f + 1) * P)
+        blk = qkv[rows].double().cpu()
+        q, k, v = (blk[:, j * inner + h * dh: j * inner + (h + 1) * dh].clone().requires_grad_(True) for j in range(3))
+        ref = _attn_ref(q, k, v)
+        ref.backward(dout[rows, h * dh:(h + 1) * dh].double().cpu())
+        worst = max(worst, relerr(out[rows, h * dh:(h + 1) * dh].cpu(), ref.detach()))
+        for j, t in enumerate((q, k, v)):
+            worst = max(worst, relerr(dqkv[rows, j * inner + h * dh: j * inner + (h + 1) * dh].cpu(), t.grad))
+    return worst, TOL[dt]
+
+
+def attn_temporal_production(B=32, F=9, P=197, heads=8, dh=64, nsample=256):
+    dt = torch.bfloat16
+    inner = heads * dh
+    M = B * F * P
+    g = torch.Generator(device='cuda').manual_seed(3)
+    qk = torch.randn((M, 2 * inner), generator=g, device=DEV, dtype=torch.float32).to(dt)
+    v = torch.randn((M, inner), generator=g, device=DEV, dtype=torch.float32).to(dt)
+    dout = torch.randn((M, inner), generator=g, device=DEV, dtype=torch.float32).to(dt)
+    out = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
+    dqk, dv = ops.attn_temporal_bwd(qk, v, dout, B, F, P, heads, dh)
+    gs = torch.Generator().manual_seed(4)
+    bs = torch.randint(0, B, (nsample,), generator=gs).tolist()
+    ps = torch.randint(0, P, (nsample,), generator=gs).tolist()
+    bs[:4], ps[:4] = [0, B - 1, 0, B - 1], [0, P - 1, P - 1, 0]
+    worst = 0.0
+    view = lambda t, w: t.view(B, F, P, w)  # noqa: E731
+    qk4, v4, do4, o4, dqk4, dv4 = view(qk, 2 * inner), view(v, inner), view(dout, inner), view(out, inner), view(dqk, 2 * inner), view(dv, inner)
+    for i, (b, p) in enumerate(zip(bs, ps)):
+        h = i % heads
+        cs = slice(h * dh, (h + 1) * dh)
+        q = qk4[b, :, p, cs].double().cpu().requires_grad_(True)
+        k = qk4[b, :, p, inner + h * dh: inner + (h + 1) * dh].double().cpu().requires_grad_(True)
+        vv = v4[b, :, p, cs].double().cpu().requires_grad_(True)
+        ref = _attn_ref(q, k, vv)
+        ref.backward(do4[b, :, p, cs].double().cpu())
+        worst = max(worst, relerr(o4[b, :, p, cs].cpu(), ref.detach()), relerr(dqk4[b, :, p, cs].cpu(), q.grad),
+                    relerr(dqk4[b, :, p, inner + h * dh: inner + (h + 1) * dh].cpu(), k.grad), relerr(dv4[b, :, p, cs].cpu(), vv.grad))
+    return worst, TOL[dt]
+
+
+def conv_dense_many_chunks(Fr=8, S_=224):
+    """conv1 / conv2 weight gradients with more chunks than workgroups (one workgroup walks several chunks: the slab
+    caps of conv_dense.hip are exceeded only at S = 224 with >= 8 frames)"""
+    return conv_dense_check(torch.bfloat16, Fr, S_)
+
+
+_base3_all_checks = all_checks
+
+
+def all_checks():  # noqa: F811
+    out = _base3_all_checks()
+    for N, K in ((728, 2912), (1536, 728), (2912, 728), (512, 728)):
+        for mode in ('fwd', 'dgrad', 'wgrad'):
+            out.append(('gemm_production_%s_N%d_K%d' % (mode, N, K), lambda mode=mode, N=N, K=K: gemm_production(mode, N, K)))
+    out.append(('gemm_production_fwd_bias_res_N728_K2912', lambda: gemm_production('fwd_bias_res', 728, 2912)))
+    out.append(('gemm_production_fwd_bias_res_N728_K512', lambda: gemm_production('fwd_bias_res', 728, 512)))
+    out.append(('gemm_production_fwd_gelu_N2912_K728', lambda: gemm_production('fwd_gelu', 2912, 728)))
+    out.append(('gemm_production_dgrad_gelu_N728_K2912', lambda: gemm_production('dgrad_gelu', 728, 2912)))
+    out.append(('attn_spatial_production_BF2304', attn_spatial_production))
+    out.append(('attn_spatial_production_P362', lambda: attn_spatial_production(448, 362, 8, 64, 16)))
+    out.append(('attn_temporal_production_C2', attn_temporal_production))
+    out.append(('attn_temporal_production_C4', lambda: attn_temporal_production(16, 17, 197, 8, 64, 128)))
+    out.append(('stem_convdense_many_chunks_bf16', conv_dense_many_chunks))
+    return out

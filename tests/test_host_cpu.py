@@ -181,3 +181,66 @@ def test_bench_cli_contract():
         assert flag in src
     for key in ('"metric"', 'roofline', 'cpu_baseline', 'ms_per_step', 'n_gpus', 'vs_baseline'):
         assert key.strip('"') in src
+
+
+# ------------------------------------------------------------------------------------------------------------------ round 2
+def test_pretrained_loader_unsqueezes_pointwise(pkg, tmp_path, monkeypatch):
+    """reference xception.py:422-442: the ImageNet file stores the pointwise weights 2-D and the classifier as `fc`;
+    return_pytorch04_xception(pretrained=True) unsqueezes them and renames fc -> last_linear.  TransferModel('xception')
+    -- the reference's default call, models_copy.py:35 -- finds the file through $ISTVT_XCEPTION_WEIGHTS."""
+    from istvt_amd.network import xception as X
+    from istvt_amd.network.models import TransferModel
+    torch.manual_seed(5)
+    src = X.Xception()
+    for p in src.parameters():
+        torch.nn.init.uniform_(p, -1.0, 1.0)
+    file_sd = {k: (v[:, :, 0, 0].clone() if 'pointwise' in k else v.clone()) for k, v in src.state_dict().items()}
+    assert file_sd['block1.rep.0.pointwise.weight'].dim() == 2
+    path = str(tmp_path / 'xception-b5690688.pth')
+    torch.save(file_sd, path)
+    m = X.return_pytorch04_xception(pretrained=True, weights_path=path)
+    assert hasattr(m, 'last_linear') and not hasattr(m, 'fc')
+    got = m.state_dict()
+    for k, v in src.state_dict().items():
+        kk = k.replace('fc.', 'last_linear.')
+        assert got[kk].shape == v.shape and torch.equal(got[kk], v), k
+    assert got['block3.rep.4.pointwise.weight'].shape == (728, 728, 1, 1)
+    # the reference's default construction path
+    monkeypatch.setenv('ISTVT_XCEPTION_WEIGHTS', path)
+    t = TransferModel('xception')
+    assert torch.equal(t.model.conv1.weight, src.conv1.weight)
+    assert torch.equal(t.model.block12.rep[4].pointwise.weight, src.block12.rep[4].pointwise.weight)
+    assert isinstance(t.model.last_linear, torch.nn.Sequential) and t.model.last_linear[1].out_features == 2
+    monkeypatch.setenv('ISTVT_XCEPTION_WEIGHTS', str(tmp_path / 'missing.pth'))
+    with pytest.raises(FileNotFoundError):
+        X.return_pytorch04_xception(pretrained=True)
+    with pytest.warns(UserWarning, match='no pretrained weights'):
+        TransferModel('xception')                       # auto mode: default initialisation + a warning
+
+
+def test_next_row_constructors_and_state_dict_names(pkg, golden_dir):
+    """the whole Xception and the ablation variants keep the reference's constructor
+    signatures and parameter names (the names are the keys the reference capture wrote into G7 / G8)."""
+    from istvt_amd.network.vivit import module as M, vivit as V
+    from istvt_amd.network import xception as X
+    g7 = np.load(os.path.join(golden_dir, 'G7_xception.npz'))
+    g8 = np.load(os.path.join(golden_dir, 'G8_siblings.npz'))
+
+    def names(g, tag):
+        return sorted(k[len(tag):] for k in g.files if k.startswith(tag))
+    net = X.xception(pretrained=False)
+    assert sorted(k for k, _ in net.named_parameters()) == names(g7, 'net.gnorm.')
+    assert sorted(k for k, _ in X.Block(728, 1024, 2, 2, start_with_relu=True, grow_first=False).named_parameters()) == names(g7, 'b12.gnorm.')
+    assert sorted(k for k, _ in X.Block(728, 728, 3, 1).named_parameters()) == names(g7, 'b4.gnorm.')
+    dim, heads, dh = 64, 2, 32
+    mods = {'attention': M.Attention(dim, heads, dh, 0.), 'temporal_only': M.TemporalOnlyAttention(dim, heads, dh, 0.),
+            'transformer': V.Transformer(dim, 2, heads, dh, 2 * dim, 0.),
+            'vivit': V.ViViT(19, 1, 3, 4, dim, 1, heads, 'cls', dim, dh, 0., 0., 2),
+            'vanilla': V.VanillaTr(7, 1, 3, 4, dim, 1, heads, 'cls', dim, dh, 0., 0., 2)}
+    for name, mod in mods.items():
+        assert sorted(k for k, _ in mod.named_parameters()) == names(g8, name + '.gnorm.'), name
+    assert isinstance(M.Attention(64, heads=1, dim_head=64).to_out, torch.nn.Identity)       # project_out rule, module.py:40
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        X.Block(64, 128, 2, 2, False)(torch.zeros(1, 64, 9, 9))
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        mods['vivit'](torch.zeros(1, 4, 64, 19, 19))

@@ -6,8 +6,10 @@
 * C1 / 224^2 geometries (which the reference cannot run) against the
   oracle, which is pinned to the reference at grid 19 and differs only by the integer P.
 Tolerances (float32 parity mode): logits rtol 1e-3 (BASELINE.json north_star); gradient norms
-2e-2 (a few ReLU/maxpool decisions at |z| ~ 1e-6 land differently under another fp32 summation
-order and each moves early stem gradients by O(1e-3..1e-2), see DESIGN.md "Parity").
+against the oracle 2e-2 (a few ReLU/maxpool decisions at |z| ~ 1e-6 land differently under another fp32 summation
+order and each moves early stem gradients by O(1e-3..1e-2), see DESIGN.md "Parity"); against the reference golden G5
+the criterion is relative to the reference's own float32-vs-float64 spread (golden G5b).
+bfloat16 (what bench.py runs): stated per test below.
 """
 import os
 
@@ -60,27 +62,27 @@ def test_g5_native_end_to_end_hip(golden_dir):
     named = dict(model.named_parameters())
     got = sorted(k for k, p in named.items() if p.grad is not None)
     assert got == sorted(live)                        # the 19.7 M dead Xception params get no gradient
-    # relative 2e-2 plus an absolute floor of 2e-6 x the largest gradient norm: with these recipe
-    # weights some temporal softmaxes are saturated and their to_qk gradients sit at 1e-7..1e-5,
-    # seven orders below the rest, i.e. at the fp32 noise floor of p*(dp - delta) -- the
-    # reference's own fp32 value for layers.6.0.fn.to_qk.weight is 7 % off its fp64 value.
-    # For exactly those tensors (the temporal blocks' to_qk weights, '.0.fn.to_qk.weight') the relative bound is the
-    # reference's own float32-vs-float64 spread, 8e-2: any reordering of float32 operations upstream (e.g. folding
-    # 1/rowsum into the exponent in the spatial attention backward) moves them by per cents: layer 5 sat inside 2e-2
-    # before such a change and sits 3.1 % from the golden after it.
-    gmax = max(float(g['gnorm.' + k]) for k in live)
-
-    def rtol(k):
-        return 8e-2 if k.endswith('.0.fn.to_qk.weight') else 2e-2
-
-    bad = [(k, float(named[k].grad.norm()), float(g['gnorm.' + k])) for k in live
-           if abs(float(named[k].grad.norm()) - float(g['gnorm.' + k])) > rtol(k) * float(g['gnorm.' + k]) + 2e-6 * gmax]
-    assert not bad, bad[:8]
+    # Gradient criterion, per tensor, against the FLOAT64 run of the reference (golden G5b): the HIP float32 path may
+    # be off the float64 truth by at most 3x what the reference's own float32 run is off it, plus a floor of 5e-3 of
+    # the tensor's norm (tensors where the reference's float32 error happens to be ~0) and 2e-6 of the largest norm
+    # (saturated temporal softmaxes leave some to_qk gradients 7 orders below the rest, at the float32 noise floor of
+    # p * (dp - delta): the reference's own float32 value of layers.6.0.fn.to_qk.weight is 7 % off its float64 value).
+    g64 = np.load(os.path.join(golden_dir, 'G5b_native_fp64.npz'))
+    assert relerr(logits, g64['logits64']) < 1e-3
+    gmax = max(float(g64['gnorm64.' + k]) for k in live)
+    rows = []
+    for k in live:
+        got, r32, r64 = float(named[k].grad.norm()), float(g['gnorm.' + k]), float(g64['gnorm64.' + k])
+        bound = 3.0 * abs(r32 - r64) + 5e-3 * r64 + 2e-6 * gmax
+        rows.append((abs(got - r64) / bound, k, got, r32, r64))
+    rows.sort(reverse=True)
+    print('G5 worst |hip - ref64| / (3 |ref32 - ref64| + 5e-3 |ref64| + 2e-6 gmax):', rows[:6])
+    assert rows[0][0] <= 1.0, rows[:6]
     for k in g.files:
-        if k.startswith('grad.'):          # 64-entry slices; same relative + noise-floor criterion
+        if k.startswith('grad.'):          # 64-entry slices, same criterion elementwise-in-norm
             got_s = named[k[5:]].grad.reshape(-1)[:64].double().cpu()
-            ref_s = torch.from_numpy(g[k]).double()
-            assert float((got_s - ref_s).norm()) <= rtol(k[5:]) * float(ref_s.norm()) + 1e-7 * gmax, k
+            r32, r64 = torch.from_numpy(g[k]).double(), torch.from_numpy(g64['grad64.' + k[5:]]).double()
+            assert float((got_s - r64).norm()) <= 3.0 * float((r32 - r64).norm()) + 5e-3 * float(r64.norm()) + 1e-7 * gmax, k
     opt.step()
     for k in g.files:
         if k.startswith('after_sgd.'):
@@ -285,7 +287,8 @@ def test_fused_optimizers_match_torch():
     init = [torch.randn(s, generator=gen) for s in shapes]
     grads = [[torch.randn(s, generator=gen) for s in shapes] for _ in range(3)]
     cases = [('sgd', dict(lr=1e-3, momentum=0.9)), ('sgd', dict(lr=5e-2, momentum=0.8, weight_decay=1e-2, nesterov=True)),
-             ('sgd', dict(lr=1e-2, momentum=0.5, dampening=0.3)), ('adamw', dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+             ('sgd', dict(lr=1e-2, momentum=0.5, dampening=0.3)), ('sgd', dict(lr=1e-2, momentum=0.0, dampening=0.3)),
+             ('adamw', dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                                                                                  weight_decay=1e-2))]
     for kind, kw in cases:
         for fz in (False, True):
@@ -367,3 +370,237 @@ def test_gemm_224_row_tile_variant():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------------------------ round 2
+# The benchmarked configuration is bfloat16 at depth 12: the tests below tie THAT path to the reference goldens, to the
+# oracle and to the float32 HIP path (which is itself golden-pinned above).
+BF16_LOGIT_TOL = 3e-2          # of max(1, |logit|): SURVEY section 6 measured 0.8-1.0e-2 for bf16 autocast of the reference at depth 12
+
+
+def test_g6_fullwidth_bf16_vs_reference_golden(golden_dir):
+    """G6 (DSTTr(19,1,1,8,depth=2), dim 728) run in bfloat16 against the reference's float32 capture."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network.vivit import vivit as V
+    g = np.load(os.path.join(golden_dir, 'G6_fullwidth.npz'))
+    mod = V.DSTTr(19, 1, 1, 8, depth=2, compute_dtype=torch.bfloat16)
+    sd = mod.state_dict()
+    mod.load_state_dict({k: torch.from_numpy(recipe.param_value('vit.' + k, tuple(v.shape))) for k, v in sd.items()})
+    mod = mod.cuda().train()
+    x = torch.from_numpy(recipe.input_value('g6.x', (1, 8, 728, 19, 19))).cuda().requires_grad_(True)
+    y = mod(x)
+    y.sum().backward()
+    d = float((y.detach().cpu() - torch.from_numpy(g['logits'])).abs().max())
+    print('G6 bf16: logits', y.detach().cpu().view(-1).tolist(), 'reference', g['logits'].reshape(-1).tolist())
+    assert d <= BF16_LOGIT_TOL * max(1.0, float(np.abs(g['logits']).max()))
+    errs = sorted(((relerr(p.grad.norm(), g['gnorm.' + k]), k) for k, p in mod.named_parameters()), reverse=True)
+    print('G6 bf16 worst gradient-norm errors:', errs[:5])
+    gmax = max(float(g['gnorm.' + k]) for k, _ in mod.named_parameters())
+    bad = [(e, k) for e, k in errs if e > 0.1 and float(g['gnorm.' + k]) > 1e-4 * gmax]
+    assert not bad, bad[:5]
+
+
+def test_g5_native_bf16_vs_reference_golden(golden_dir):
+    """G5 (the reference-native model: T=6, 300^2, depth 12) run in bfloat16 against the reference's capture: logit,
+    loss and the transformer's gradient norms.  The recipe's sin-wave stem weights make the BatchNorm chain amplify
+    rounding ~2x per layer (DESIGN.md "Parity"), so the stem's own bf16 gradients are judged with well-conditioned
+    weights in test_depth12_bf16_vs_oracle below."""
+    XceptionVidTr, model_selection = _load()
+    g = np.load(os.path.join(golden_dir, 'G5_native.npz'))
+    model = load_recipe(XceptionVidTr(compute_dtype=torch.bfloat16))
+    x = torch.from_numpy(recipe.input_value('g5.x', (1, 6, 3, 300, 300))).cuda()
+    logits = model(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits.view(-1), torch.ones(1, device='cuda'))
+    loss.backward()
+    print('G5 bf16: logit %.5f (reference %.5f), loss %.5f (reference %.5f)'
+          % (float(logits), float(g['logits'].reshape(-1)[0]), float(loss), float(g['loss'])))
+    assert abs(float(logits) - float(g['logits'].reshape(-1)[0])) <= 0.1 * max(1.0, abs(float(g['logits'].reshape(-1)[0])))
+    named = dict(model.named_parameters())
+    live = [str(s) for s in g['live_param_names']]
+    assert sorted(k for k, p in named.items() if p.grad is not None) == sorted(live)
+    assert all(torch.isfinite(named[k].grad).all() for k in live)
+
+
+def _bucket_grads(model):
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    return parallel.live_named_parameters(model)
+
+
+def test_depth12_fp32_and_bf16_vs_oracle():
+    """The full-depth model at the benchmark geometry (T=8, 224^2 -> 14x14, depth 12), B=4, default-style random init:
+    HIP float32 against the oracle (logits rtol 1e-3, gradient norms 2e-2), then HIP bfloat16 -- the dtype bench.py
+    runs -- against the same oracle run: logits within BF16_LOGIT_TOL, loss, and every gradient as a direction
+    (cosine) and in norm."""
+    R, p, x, labels, grid = _oracle_case(4, 8, 224, 12, seed=2)
+    pr = R.with_grad(p)
+    ref = R.xception_vidtr_forward(pr, x, depth=12)
+    ref_loss = R.bce_with_logits(ref, labels)
+    ref_loss.backward()
+    m32 = _hip_model(p, 8, grid, 12)
+    out = m32(x.cuda())
+    torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+    assert relerr(out, ref) < 1e-3
+    n32 = dict(m32.named_parameters())
+    errs = sorted(((relerr(n32[k].grad.norm(), v.grad.norm()), k) for k, v in pr.items() if v.requires_grad and v.grad is not None),
+                  reverse=True)
+    print('depth-12 fp32 worst gradient-norm errors vs oracle:', errs[:4])
+    assert errs[0][0] < 2e-2, errs[:5]
+    del m32, n32
+    m16 = _hip_model(p, 8, grid, 12, dtype=torch.bfloat16)
+    o16 = m16(x.cuda())
+    l16 = torch.nn.functional.binary_cross_entropy_with_logits(o16.view(-1), labels.cuda())
+    l16.backward()
+    d = float((o16.detach().cpu() - ref.detach()).abs().max())
+    print('depth-12 bf16: max |dlogit| %.4e (max |logit| %.3f), loss %.5f vs %.5f' % (d, float(ref.abs().max()), float(l16), float(ref_loss)))
+    assert d <= BF16_LOGIT_TOL * max(1.0, float(ref.abs().max()))
+    assert abs(float(l16) - float(ref_loss)) <= 2e-2 * max(1.0, float(ref_loss))
+    n16 = dict(m16.named_parameters())
+    rows = []
+    for k, v in pr.items():
+        if v.requires_grad and v.grad is not None:
+            a, b = n16[k].grad.double().cpu().flatten(), v.grad.double().flatten()
+            rows.append((1.0 - float(torch.nn.functional.cosine_similarity(a, b, dim=0)), abs(float(a.norm() / b.norm()) - 1.0), k))
+    rows.sort(reverse=True)
+    print('depth-12 bf16 worst gradient directions (1 - cos, |norm ratio - 1|):', rows[:5])
+    assert rows[0][0] < 0.05, rows[:5]                      # every gradient within ~18 degrees of the float32 truth
+    assert max(r[1] for r in rows) < 0.15, sorted(rows, key=lambda r: -r[1])[:5]
+
+
+def test_c2_full_step_bf16_bounded_by_fp32():
+    """ONE step of exactly what bench.py times (C2: B=32, T=8, 224^2, depth 12, bf16, fused bucket) against the same step
+    of the float32 HIP path (golden-pinned above): logits, loss and the flat gradient bucket."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    XceptionVidTr, _ = _load()
+    B, T = 32, 8
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((B, T, 3, 224, 224), generator=g).cuda()
+    labels = (torch.rand((B,), generator=g) > 0.5).float().cuda()
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        model = XceptionVidTr(num_frames=T, grid=14, depth=12, compute_dtype=dt).cuda().train()
+        live = [q for _, q in parallel.live_named_parameters(model)]
+        bucket = parallel.GradBucket(live, fuse_accumulate=True)
+        bucket.zero()
+        logits = model(x)
+        loss = torch.nn.BCEWithLogitsLoss()(logits.view(-1), labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[dt] = (logits.detach().float().cpu(), float(loss), bucket.flat.clone().cpu())
+        del model, bucket, live, logits, loss
+        torch.cuda.empty_cache()
+    (y32, l32, g32), (y16, l16, g16) = res[torch.float32], res[torch.bfloat16]
+    d = float((y16 - y32).abs().max())
+    cos = float(torch.nn.functional.cosine_similarity(g16.double(), g32.double(), dim=0))
+    print('C2 step bf16 vs fp32: max |dlogit| %.4e (max |logit| %.3f), loss %.5f vs %.5f, bucket cosine %.5f, norm ratio %.4f'
+          % (d, float(y32.abs().max()), l16, l32, cos, float(g16.norm() / g32.norm())))
+    assert d <= BF16_LOGIT_TOL * max(1.0, float(y32.abs().max()))
+    assert abs(l16 - l32) <= 1e-2 * max(1.0, l32)
+    assert cos > 0.98
+    assert abs(float(g16.norm() / g32.norm()) - 1.0) < 0.05
+
+
+def test_failed_backward_does_not_poison_the_side_stream_join():
+    """a backward that aborts after its first side-stream weight gradient must not leave the join state set:
+    the next, normal step has to register its end-of-backward join again and give the single-stream gradients."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import functional as Fn, parallel
+    R, p, x, labels, grid = _oracle_case(2, 4, 96, 2)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError('boom')
+
+    results = []
+    try:
+        for overlap in (False, True):
+            Fn.set_wgrad_overlap(overlap)
+            model = _hip_model(p, 4, grid, 2)
+            live = parallel.live_named_parameters(model)
+            bucket = parallel.GradBucket([q for _, q in live], fuse_accumulate=True)
+            if overlap:
+                # abort a backward in the middle of the transformer: the head / last layers have already enqueued
+                # weight gradients on the side stream when the stem's output gradient reaches Boom
+                feats = model.xcep.model.low_level_features_nhwc(x.cuda().flatten(0, 1), torch.float32)
+                n, h, w, c = feats.shape
+                out = model.vit.forward_features(Boom.apply(feats).view(2, 4, h * w, c))
+                with pytest.raises(RuntimeError, match='boom'):
+                    out.sum().backward()
+            bucket.zero()
+            out = model(x.cuda())
+            torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+            results.append(bucket.flat.clone())
+            if overlap:
+                assert not Fn._overlap['pending'], 'join state left behind'
+                assert not Fn._overlap['keep'], 'operands kept alive past the join'
+    finally:
+        Fn.set_wgrad_overlap(True)
+    assert float(results[0].norm()) > 0
+    assert relerr(results[1], results[0]) < 1e-5
+
+
+def test_fused_optimizers_are_torch_optimizers():
+    """the fused optimizers drop into the reference loop (train_CNN.py:196-202): lr schedulers drive them
+    through param_groups, state_dict() / load_state_dict() checkpoint the flat state, and the data-parallel 1 / W is
+    folded into the step kernel (GradBucket.defer_scale) instead of a pass over the bucket."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    gen = torch.Generator().manual_seed(3)
+    init = [torch.randn(s, generator=gen) for s in [(37, 5), (1001,), (8, 3, 3, 3)]]
+    grads = [[torch.randn(t.shape, generator=gen) for t in init] for _ in range(4)]
+
+    def make(kind):
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        b = parallel.GradBucket(ps, flatten_params=True)
+        o = parallel.FusedSGD(b, lr=0.1, momentum=0.9, zero_grad=True) if kind == 'sgd' else parallel.FusedAdamW(b, lr=0.1, zero_grad=True)
+        return ps, b, o
+    for kind in ('sgd', 'adamw'):
+        ref_p = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        ref = torch.optim.SGD(ref_p, lr=0.1, momentum=0.9) if kind == 'sgd' else torch.optim.AdamW(ref_p, lr=0.1)
+        ps, b, o = make(kind)
+        assert isinstance(o, torch.optim.Optimizer) and b.defer_scale
+        s_ref = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=4)
+        s_my = torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=4)
+        saved = None
+        lrs_used = []
+        for step in range(4):
+            lrs_used.append(o.param_groups[0]['lr'])
+            o.zero_grad()
+            for p_, q_, gv in zip(ref_p, ps, grads[step]):
+                p_.grad = gv.clone().cuda()
+                q_.grad.add_(2.0 * gv.cuda())          # the SUM over a 2-rank world ...
+            b.grad_scale = 0.5                          # ... which the step kernel turns into the mean
+            ref.step(); o.step()
+            s_ref.step(); s_my.step()
+            assert abs(o.param_groups[0]['lr'] - ref.param_groups[0]['lr']) < 1e-12
+            assert b.grad_scale == 1.0
+            for p_, q_ in zip(ref_p, ps):
+                assert relerr(q_, p_) < 5e-6, (kind, step)
+            if step == 1:
+                saved = (o.state_dict(), [q_.detach().clone() for q_ in ps])
+        # resume from the step-1 checkpoint into a fresh optimizer: steps 2 and 3 reproduce the parameters
+        ps2, b2, o2 = make(kind)
+        for q_, v in zip(ps2, saved[1]):
+            q_.data.copy_(v)
+        o2.load_state_dict(saved[0])
+        for step in (2, 3):
+            o2.zero_grad()
+            for q_, gv in zip(ps2, grads[step]):
+                q_.grad.add_(gv.cuda())
+            o2.param_groups[0]['lr'] = lrs_used[step]
+            o2.step()
+        assert o2.steps == 4
+        for q_, r_ in zip(ps2, ps):
+            assert relerr(q_, r_) < 1e-6, kind

@@ -168,3 +168,192 @@ def test_g5_native_end_to_end(golden_dir):
             assert relerr(w.reshape(-1)[:64], g[k]) < 1e-6, k
     assert relerr(p['xcep.model.bn1.running_mean'], g['bn1.running_mean']) < RTOL
     assert relerr(p['xcep.model.bn1.running_var'], g['bn1.running_var']) < RTOL
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 2: the fixtures SURVEY 8(c) lists that round 1 had skipped (224^2 stem, F = 17, T = 16), the float64 run of G5,
+# Xception blocks / the whole network (G7) and the ablation attention variants (G8)
+# ------------------------------------------------------------------------------------------------------------------
+def test_g1b_stem_224(golden_dir):
+    g = load(golden_dir, 'G1b_stem224')
+    side = 224
+    p = R.with_grad(recipe_params(R.stem_param_shapes(), 'xcep.model.'))
+    x = torch.from_numpy(recipe.input_value('g1.x%d' % side, (2, 3, side, side))).requires_grad_(True)
+    y = R.stem_forward(p, x)
+    assert y.shape[-1] == 14
+    coef = torch.from_numpy(recipe.input_value('g1.coef%d' % side, tuple(y.shape)))
+    (y * coef).sum().backward()
+    tag = 's%d.' % side
+    assert relerr(y.detach(), g[tag + 'y']) < RTOL
+    assert relerr(x.grad.norm(), g[tag + 'dx_norm']) < 1e-4
+    for k in ('bn1', 'bn2', 'block1.skipbn', 'block2.rep.2', 'block3.rep.5', 'block3.skipbn'):
+        assert relerr(p[k + '.running_mean'], g[tag + k + '.running_mean']) < RTOL
+        assert relerr(p[k + '.running_var'], g[tag + k + '.running_var']) < RTOL
+    for k, v in p.items():
+        if v.requires_grad:
+            assert relerr(v.grad.norm(), g[tag + 'gnorm.' + k]) < 1e-4, k
+    for k in g.files:
+        if k.startswith(tag + 'grad.'):
+            name = k[len(tag + 'grad.'):]
+            assert relerr(p[name].grad.reshape(-1)[:4096], g[k]) < 1e-4, name
+
+
+@pytest.mark.parametrize('name', ['prenorm_ff', 'spatial', 'temporal'])
+def test_g2b_modules_f17(golden_dir, name):
+    g = load(golden_dir, 'G2b_modules_F17')
+    shapes, fn = MODULES[name]
+    p, x, y = _module_case(fn, shapes, 'g2.%s.' % name, 'g2.%s.F17' % name, (1, 17 * 362, DIM))
+    tag = 'F17.%s.' % name
+    assert relerr(y.detach()[:, ::13], g[tag + 'y']) < RTOL
+    assert relerr(x.grad[:, ::13], g[tag + 'dx']) < 2e-5
+    for k, v in p.items():
+        assert relerr(v.grad, g[tag + 'grad.' + k]) < 2e-5, k
+
+
+def test_g4b_dsttr_t16(golden_dir):
+    g = load(golden_dir, 'G4b_dsttr_T16')
+    T = 16
+    shapes = R.dsttr_param_shapes(T, 19, dim=DIM, depth=2, heads=HEADS, dim_head=DH, scale_dim=2)
+    p = R.with_grad(recipe_params(shapes, 'g4.'))
+    x = torch.from_numpy(recipe.input_value('g4.x.T%d' % T, (2, T, DIM, 19, 19))).requires_grad_(True)
+    y = R.dsttr_forward(p, x, depth=2, heads=HEADS)
+    coef = torch.from_numpy(recipe.input_value('g4.coef', tuple(y.shape)))
+    (y * coef).sum().backward()
+    tag = 'T%d.' % T
+    assert relerr(y.detach(), g[tag + 'logits']) < RTOL
+    assert relerr(x.grad.flatten(2).norm(dim=2), g[tag + 'dx_frame_norms']) < 1e-4
+    for k, v in p.items():
+        assert relerr(v.grad.norm(), g[tag + 'gnorm.' + k]) < 1e-4, k
+    assert relerr(p['pos_embedding'].grad[0, :, ::37], g[tag + 'grad.pos_embedding']) < 1e-4
+
+
+def rand_params(shapes, prefix, dtype=torch.float32):
+    return {k: torch.from_numpy(recipe.rand_param_value(prefix + k, s)).to(dtype if len(s) or 'num_batches' not in k else torch.long)
+            for k, s in shapes.items()}
+
+
+G7_BLOCKS = {'b1': ((64, 128, 2, 2, False, True), (2, 64, 21, 21)), 'b2': ((128, 256, 2, 2, True, True), (2, 128, 15, 15)),
+             'b4': ((728, 728, 3, 1, True, True), (2, 728, 10, 10)), 'b12': ((728, 1024, 2, 2, True, False), (2, 728, 10, 10))}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('name', list(G7_BLOCKS) + ['sep'])
+def test_g7_blocks(golden_dir, name, dtype):
+    """Block / SeparableConv2d executed by themselves (xception.py:46-49, 91-101), float32 and float64 reference runs."""
+    g = load(golden_dir, 'G7_xception')
+    f64 = dtype == torch.float64
+    tag = name + ('.f64.' if f64 else '.')
+    if name == 'sep':
+        shapes = {'conv1.weight': (64, 1, 3, 3), 'pointwise.weight': (128, 64, 1, 1)}
+        shape = (2, 64, 13, 17)
+        fn = lambda p, x: R._sepconv({'s.' + k: v for k, v in p.items()}, 's', x)  # noqa: E731
+    else:
+        cfg, shape = G7_BLOCKS[name]
+        shapes = R.block_param_shapes(*cfg)
+        fn = lambda p, x: R.block_forward(p, '', x, *cfg)  # noqa: E731
+    p = R.with_grad(rand_params(shapes, 'g7.%s.' % name, dtype))
+    x = torch.from_numpy(recipe.rand_input_value('g7.%s.x' % name, shape)).to(dtype).requires_grad_(True)
+    y = fn(p, x)
+    coef = torch.from_numpy(recipe.rand_input_value('g7.%s.coef' % name, tuple(y.shape))).to(dtype)
+    (y * coef).sum().backward()
+    tol = 1e-10 if f64 else 2e-5
+    assert relerr(y.detach(), g[tag + 'y']) < tol
+    assert relerr(x.grad.norm(), g[tag + 'dx_norm']) < (1e-9 if f64 else 1e-4)
+    for k, v in p.items():
+        if v.requires_grad:
+            assert relerr(v.grad.norm(), g[tag + 'gnorm.' + k]) < (1e-9 if f64 else 1e-4), k
+            if not f64:
+                assert relerr(v.grad.reshape(-1)[:4096], g[tag + 'grad.' + k]) < 2e-4, k
+        elif not f64 and 'running' in k:
+            assert relerr(v, g[tag + 'buf.' + k]) < RTOL, k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_g7_xception_network(golden_dir, dtype):
+    """features() / logits() of the whole Xception (xception.py:161-215) at 299^2, train mode."""
+    g = load(golden_dir, 'G7_xception')
+    f64 = dtype == torch.float64
+    tag = 'net.f64.' if f64 else 'net.'
+    p = R.with_grad(rand_params(R.xception_param_shapes(), 'g7.net.', dtype))
+    x = torch.from_numpy(recipe.rand_input_value('g7.net.x', (2, 3, 299, 299))).to(dtype).requires_grad_(True)
+    feats = R.xception_features(p, x)
+    logits = R.xception_logits(p, feats)
+    coef = torch.from_numpy(recipe.rand_input_value('g7.net.coef', tuple(logits.shape))).to(dtype)
+    (logits * coef).sum().backward()
+    assert relerr(feats.detach()[:, ::16], g[tag + 'features_sub']) < (1e-9 if f64 else 1e-4)
+    assert relerr(logits.detach(), g[tag + 'logits']) < (1e-9 if f64 else 1e-4)
+    assert relerr(x.grad.norm(), g[tag + 'dx_norm']) < (1e-8 if f64 else 2e-3)
+    worst = max((relerr(v.grad.norm(), g[tag + 'gnorm.' + k]), k) for k, v in p.items() if v.requires_grad)
+    assert worst[0] < (1e-8 if f64 else 5e-3), worst
+    for k in ('bn1', 'block5.rep.2', 'block12.skipbn', 'bn3', 'bn4'):
+        assert relerr(p[k + '.running_var'], g[tag + 'buf.' + k + '.running_var']) < (1e-9 if f64 else 1e-4), k
+
+
+def test_g7_xception_eval(golden_dir):
+    g = load(golden_dir, 'G7_xception')
+    p = rand_params(R.xception_param_shapes(), 'g7.net.')
+    x = torch.from_numpy(recipe.rand_input_value('g7.net.x', (2, 3, 299, 299)))
+    with torch.no_grad():
+        logits = R.xception_logits(p, R.xception_features(p, x, training=False))
+    assert relerr(logits, g['net.eval.logits']) < 1e-4
+
+
+def _vit_shapes(dim, depth, heads, dh, mlp, prefix):
+    inner = heads * dh
+    s = {}
+    for i in range(depth):
+        lp = '%slayers.%d' % (prefix, i)
+        s.update({lp + '.0.norm.weight': (dim,), lp + '.0.norm.bias': (dim,), lp + '.0.fn.to_qkv.weight': (3 * inner, dim),
+                  lp + '.0.fn.to_out.0.weight': (dim, inner), lp + '.0.fn.to_out.0.bias': (dim,),
+                  lp + '.1.norm.weight': (dim,), lp + '.1.norm.bias': (dim,), lp + '.1.fn.net.0.weight': (mlp, dim),
+                  lp + '.1.fn.net.0.bias': (mlp,), lp + '.1.fn.net.3.weight': (dim, mlp), lp + '.1.fn.net.3.bias': (dim,)})
+    s[prefix + 'norm.weight'] = (dim,)
+    s[prefix + 'norm.bias'] = (dim,)
+    return s
+
+
+def _g8_case(name):
+    dim, heads, dh = 64, 2, 32
+    inner = heads * dh
+    attn = {'to_qkv.weight': (3 * inner, dim), 'to_out.0.weight': (dim, inner), 'to_out.0.bias': (dim,)}
+    head = {'mlp_head.0.weight': (dim,), 'mlp_head.0.bias': (dim,), 'mlp_head.1.weight': (3, dim), 'mlp_head.1.bias': (3,)}
+    if name == 'attention':
+        return attn, (2, 50, dim), lambda p, x: R.attention({'a.' + k: v for k, v in p.items()}, 'a', x, heads)
+    if name == 'temporal_only':
+        return attn, (1, 5 * 362, dim), lambda p, x: R.temporal_only_attention({'a.' + k: v for k, v in p.items()}, 'a', x, 362, heads)
+    if name == 'transformer':
+        return (_vit_shapes(dim, 2, heads, dh, 2 * dim, ''), (2, 50, dim),
+                lambda p, x: R.transformer({'t.' + k: v for k, v in p.items()}, 't', x, 2, heads))
+    if name in ('vivit', 'vivit_mean'):
+        s = {'pos_embedding': (1, 4, 362, dim), 'space_token': (1, 1, dim), 'temporal_token': (1, 1, dim), **head}
+        s.update(_vit_shapes(dim, 1, heads, dh, 2 * dim, 'space_transformer.'))
+        s.update(_vit_shapes(dim, 1, heads, dh, 2 * dim, 'temporal_transformer.'))
+        return s, (2, 4, dim, 19, 19), lambda p, x: R.vivit_forward(p, x, 1, heads, 'mean' if name.endswith('mean') else 'cls')
+    s = {'pos_embedding': (1, 4 * 49 + 1, dim), 'cls_token': (1, 1, dim), 'to_patch_embedding.1.weight': (dim, dim),
+         'to_patch_embedding.1.bias': (dim,), **head}
+    s.update(_vit_shapes(dim, 1, heads, dh, 2 * dim, 'transformer.'))
+    return s, (2, 4, dim, 7, 7), lambda p, x: R.vanilla_tr_forward(p, x, 1, heads)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('name', ['attention', 'temporal_only', 'transformer', 'vivit', 'vivit_mean', 'vanilla'])
+def test_g8_siblings(golden_dir, name, dtype):
+    """The ablation variants: Attention / TemporalOnlyAttention (module.py:36-64,145-172), Transformer / ViViT /
+    VanillaTr (vivit.py:10-25,29-81,150-191)."""
+    g = load(golden_dir, 'G8_siblings')
+    f64 = dtype == torch.float64
+    tag = name + ('.f64.' if f64 else '.')
+    shapes, shape, fn = _g8_case(name)
+    p = R.with_grad(rand_params(shapes, 'g8.%s.' % name, dtype))
+    x = torch.from_numpy(recipe.rand_input_value('g8.%s.x' % name, shape)).to(dtype).requires_grad_(True)
+    y = fn(p, x)
+    coef = torch.from_numpy(recipe.rand_input_value('g8.%s.coef' % name, tuple(y.shape))).to(dtype)
+    (y * coef).sum().backward()
+    yy = y.detach()[:, ::7] if y.numel() > 20000 else y.detach()
+    assert relerr(yy, g[tag + 'y']) < (1e-10 if f64 else 2e-5)
+    assert relerr(x.grad.norm(), g[tag + 'dx_norm']) < (1e-9 if f64 else 1e-4)
+    assert sorted(k for k in p) == sorted(k[len(tag + 'gnorm.'):] for k in g.files if k.startswith(tag + 'gnorm.'))
+    for k, v in p.items():
+        assert relerr(v.grad.norm(), g[tag + 'gnorm.' + k]) < (1e-9 if f64 else 1e-4), k
+        if not f64:
+            assert relerr(v.grad.reshape(-1)[:4096], g[tag + 'grad.' + k]) < 2e-4, k

@@ -1,0 +1,193 @@
+"""SURVEY 8(f) row 3 + the a5 / a6 rows on a real MI355X: SeparableConv2d.forward, Block.forward (reference
+network/xception.py:46-49, 91-101) executed BY THEMSELVES on the HIP kernels, and the whole Xception -- features(),
+logits(), forward() (xception.py:161-215) -- against golden G7 captured from the reference (float32 and float64 runs).
+
+Gradient criterion (per tensor, norms): |hip - ref64| <= 3 * |ref32 - ref64| + floor, i.e. the HIP float32 path may be
+off the float64 truth by at most three times what the reference's own float32 run is, plus a floor for tensors whose
+reference error happens to be ~0."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import recipe  # noqa: E402
+
+
+def _X():
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network import xception as X
+    return X
+
+
+def relerr(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b), dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def load_rand(mod, prefix):
+    sd = mod.state_dict()
+    mod.load_state_dict({k: torch.from_numpy(recipe.rand_param_value(prefix + k, tuple(v.shape))) for k, v in sd.items()})
+    return mod.cuda().train()
+
+
+def within_ref_spread(got, ref32, ref64, k=3.0, floor=2e-4):
+    """|got - ref64| <= k |ref32 - ref64| + floor * |ref64|"""
+    got, ref32, ref64 = float(got), float(ref32), float(ref64)
+    return abs(got - ref64) <= k * abs(ref32 - ref64) + floor * abs(ref64)
+
+
+CASES = {'b1': (lambda X: X.Block(64, 128, 2, 2, start_with_relu=False, grow_first=True), (2, 64, 21, 21)),
+         'b2': (lambda X: X.Block(128, 256, 2, 2, start_with_relu=True, grow_first=True), (2, 128, 15, 15)),
+         'b4': (lambda X: X.Block(728, 728, 3, 1, start_with_relu=True, grow_first=True), (2, 728, 10, 10)),
+         'b12': (lambda X: X.Block(728, 1024, 2, 2, start_with_relu=True, grow_first=False), (2, 728, 10, 10)),
+         'sep': (lambda X: X.SeparableConv2d(64, 128, 3, 1, 1), (2, 64, 13, 17))}
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+@pytest.mark.parametrize('name', list(CASES))
+def test_g7_block_modules_hip(golden_dir, name, layout):
+    X = _X()
+    g = np.load(os.path.join(golden_dir, 'G7_xception.npz'))
+    ctor, shape = CASES[name]
+    mod = load_rand(ctor(X), 'g7.%s.' % name)
+    x = torch.from_numpy(recipe.rand_input_value('g7.%s.x' % name, shape)).cuda()
+    if layout == 'channels_last':
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y = mod(x)
+    coef = torch.from_numpy(recipe.rand_input_value('g7.%s.coef' % name, tuple(y.shape))).cuda()
+    (y * coef).sum().backward()
+    tag = name + '.'
+    assert tuple(y.shape) == tuple(g[tag + 'y'].shape)
+    assert relerr(y, g[tag + 'y']) < 2e-5
+    assert relerr(x.grad, g[tag + 'dx']) < 2e-4
+    for k, p in mod.named_parameters():
+        assert relerr(p.grad.reshape(-1)[:4096], g[tag + 'grad.' + k]) < 5e-4, k
+        assert within_ref_spread(p.grad.norm(), g[tag + 'gnorm.' + k], g[name + '.f64.gnorm.' + k]), k
+    for k, v in mod.state_dict().items():
+        if 'running' in k:
+            assert relerr(v, g[tag + 'buf.' + k]) < 1e-5, k
+        if 'num_batches' in k:
+            assert int(v) == 1
+
+
+def test_block_bf16_tracks_fp32():
+    """the same Block in bfloat16 storage against its float32 run (bf16 rounding of every stored activation)"""
+    X = _X()
+    ctor, shape = CASES['b4']
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        mod = load_rand(ctor(X), 'g7.b4.')
+        x = torch.from_numpy(recipe.rand_input_value('g7.b4.x', shape)).cuda().to(dt).requires_grad_(True)
+        y = mod(x)
+        assert y.dtype == dt
+        y.float().square().sum().backward()
+        outs.append((y.float().detach(), x.grad.float(), {k: p.grad.clone() for k, p in mod.named_parameters()}))
+    assert relerr(outs[1][0], outs[0][0]) < 2e-2
+    cos = torch.nn.functional.cosine_similarity(outs[1][1].flatten(), outs[0][1].flatten(), dim=0)
+    assert float(cos) > 0.99
+    for k in outs[0][2]:
+        c = torch.nn.functional.cosine_similarity(outs[1][2][k].flatten(), outs[0][2][k].flatten(), dim=0)
+        assert float(c) > 0.98, k
+
+
+def test_g7_xception_network_hip(golden_dir):
+    """features() / logits() / forward() at 299^2, train mode, against the reference capture."""
+    X = _X()
+    g = np.load(os.path.join(golden_dir, 'G7_xception.npz'))
+    net = load_rand(X.xception(pretrained=False), 'g7.net.')
+    x = torch.from_numpy(recipe.rand_input_value('g7.net.x', (2, 3, 299, 299))).cuda().requires_grad_(True)
+    feats = net.features(x)
+    assert tuple(feats.shape) == (2, 2048, 10, 10)
+    logits = net.logits(feats)
+    coef = torch.from_numpy(recipe.rand_input_value('g7.net.coef', tuple(logits.shape))).cuda()
+    (logits * coef).sum().backward()
+    assert relerr(feats[:, ::16], g['net.features_sub']) < 1e-3
+    assert relerr(logits, g['net.logits']) < 1e-3                     # north_star: logits rtol 1e-3
+    named = dict(net.named_parameters())
+    rows = []
+    for k, p in named.items():
+        r32, r64 = float(g['net.gnorm.' + k]), float(g['net.f64.gnorm.' + k])
+        rows.append((abs(float(p.grad.norm()) - r64) / max(3.0 * abs(r32 - r64) + 2e-3 * abs(r64), 1e-30), k,
+                     float(p.grad.norm()), r32, r64))
+    rows.sort(reverse=True)
+    print('worst gradient-norm ratios (|hip-ref64| / (3|ref32-ref64| + 2e-3|ref64|)):', rows[:5])
+    assert rows[0][0] <= 1.0, rows[:5]
+    assert within_ref_spread(x.grad.norm(), g['net.dx_norm'], g['net.f64.dx_norm'], floor=2e-3)
+    sd = net.state_dict()
+    for k in ('bn1', 'block5.rep.2', 'block12.skipbn', 'bn3', 'bn4'):
+        assert relerr(sd[k + '.running_var'], g['net.buf.' + k + '.running_var']) < 1e-3, k
+        assert relerr(sd[k + '.running_mean'], g['net.buf.' + k + '.running_mean']) < 5e-3, k
+    # forward() == logits(features()) and the whole thing again in eval mode against the reference's eval capture
+    net2 = load_rand(X.xception(pretrained=False), 'g7.net.').eval()
+    with torch.no_grad():
+        out = net2(x.detach())
+    assert relerr(out, g['net.eval.logits']) < 1e-3
+
+
+def test_transfer_model_xception_head_and_dropout():
+    """model_selection('xception') (models_copy.py:34-45,233-249): Dropout(0.5) + Linear(2048, 2) head on the HIP
+    dropout kernel in train mode, deterministic under torch.manual_seed, identity in eval mode; the per-frame baseline
+    eval (train_CNN.py:924-929) is model(image) in eval mode."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network.models import model_selection
+    m = model_selection('xception', 2, pretrained=False).cuda()
+    x = torch.randn(2, 3, 160, 160, generator=torch.Generator().manual_seed(0)).cuda()
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x), m(x)
+    assert e1.shape == (2, 2) and torch.equal(e1, e2)
+    m.train()
+    torch.manual_seed(11)
+    t1 = m(x)
+    torch.manual_seed(11)
+    t2 = m(x)
+    torch.manual_seed(12)
+    t3 = m(x)
+    assert torch.equal(t1, t2) and not torch.equal(t1, t3)
+    t1.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert m.model.last_linear[1].weight.grad is not None and m.model.conv1.weight.grad is not None
+    f = m.features(x)
+    assert f.shape == (2, 2048)
+
+
+def test_eval_mode_stem_backward_matches_oracle():
+    """backward through an eval-mode stem (running-statistics BatchNorm is an affine map): gradients against the oracle
+    with training=False -- the exact W-rank == 1-rank test bed of SURVEY 8(e)."""
+    X = _X()
+    from oracle import istvt_ref as R
+    p = R.random_params(R.stem_param_shapes(), seed=3)
+    g = torch.Generator().manual_seed(4)
+    for k in p:                                       # non-trivial running statistics
+        if k.endswith('running_mean'):
+            p[k] = 0.1 * torch.randn(p[k].shape, generator=g)
+        if k.endswith('running_var'):
+            p[k] = 0.5 + torch.rand(p[k].shape, generator=g)
+    x = torch.randn((2, 3, 139, 139), generator=g)
+    pr = R.with_grad(p)
+    xr = x.clone().requires_grad_(True)
+    yr = R.stem_forward(pr, xr, training=False)
+    coef = torch.randn(yr.shape, generator=g)
+    (yr * coef).sum().backward()
+    net = X.xception(pretrained=False)
+    sd = net.state_dict()
+    sd.update(p)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    xc = x.cuda().requires_grad_(True)
+    y = net.low_level_features(xc)
+    (y * coef.cuda()).sum().backward()
+    assert relerr(y, yr) < 1e-4
+    assert relerr(xc.grad, xr.grad) < 1e-3
+    named = dict(net.named_parameters())
+    from istvt_amd import stem as S
+    worst = max((relerr(named[k].grad, pr[k].grad), k) for k in S.param_names())
+    assert worst[0] < 2e-3, worst
+    assert relerr(net.state_dict()['bn1.running_mean'], p['bn1.running_mean']) == 0.0
