@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
     }
 }
 
+// Softmax backward without the cancellation of  dp_j - sum_l p_l dp_l : with sum_l p_l = 1 that difference is
+// sum_l p_l (dp_j - dp_l), a sum of terms that are each small when the softmax is peaked (p_max -> 1 makes dp_max - delta
+// the difference of two nearly equal numbers whose rounding errors, ~eps |dO||V|, are then amplified by 1 / (1 - p_max):
+// with the golden recipe's saturated temporal softmaxes that was per cents of the to_qk gradients).  F <= 17 keys:
+// F^2 subtractions per row are nothing next to the loads.
+template <int FMAX>
+__device__ __forceinline__ float softmax_bwd_pairwise(const float (&pr)[FMAX], const float (&dp)[FMAX], const int j, const int F) {
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < FMAX; ++l) {
+        if (l < F) acc += pr[l] * (dp[j] - dp[l]);
+    }
+    return acc;
+}
+
 // backward: dqk [B*F*P][2*inner] (dq | dk), dv [B*F*P][inner]
 template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
@@ -155,16 +170,15 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
                 if (j < F) { pr[j] = __expf(pr[j] - mx); sum += pr[j]; }
             }
             const float inv = 1.0f / sum;
-            float delta = 0.f;
 #pragma unroll
             for (int j = 0; j < FMAX; ++j) {
-                if (j < F) { pr[j] *= inv; delta += pr[j] * dp[j]; }
+                if (j < F) pr[j] *= inv;
             }
             float dq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < FMAX; ++j) {
                 if (j < F) {
-                    const float ds = pr[j] * (dp[j] - delta) * scale;
+                    const float ds = pr[j] * softmax_bwd_pairwise<FMAX>(pr, dp, j, F) * scale;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         dq[e] += ds * k[j][e];
@@ -381,10 +395,9 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
                 if (j < F) { pr[j] = __expf(pr[j] - mx); sum += pr[j]; }
             }
             const float inv = 1.0f / sum;
-            float delta = 0.f;
 #pragma unroll
             for (int j = 0; j < FMAX; ++j) {
-                if (j < F) { pr[j] *= inv; delta += pr[j] * dp[j]; }
+                if (j < F) pr[j] *= inv;
             }
             float dq[EPL];
 #pragma unroll
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
 #pragma unroll
             for (int j = 0; j < FMAX; ++j) {
                 if (j < F) {
-                    const float ds = pr[j] * (dp[j] - delta) * scale;
+                    const float ds = pr[j] * softmax_bwd_pairwise<FMAX>(pr, dp, j, F) * scale;
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         dq[e] += ds * k[j][e];

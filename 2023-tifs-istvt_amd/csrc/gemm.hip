@@ -33,8 +33,7 @@ struct GemmArgs {
     int a_vec, b_vec;     // 16-byte vector loads legal for the operand
     float alpha;
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
-    int gm;               // gemm256: row-panels per tile group (L2 locality of the tile walk)
-    int flat_splits;      // > 0: 1-D grid of 8*tiles*ceil(splits/8) workgroups, reduction slice s runs on XCD s % 8
+    int gm;               // gemm256q: row-panels per tile group (L2 locality of the tile walk)
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -100,9 +99,7 @@ __device__ __forceinline__ gf2 gelu_grad_fast2(gf2 u) {
     return (u * gf2{0.39894228040143267794f, 0.39894228040143267794f}) * e + (er * gf2{0.5f, 0.5f} + gf2{0.5f, 0.5f});
 }
 
-#include "gemm256.h"
-#include "gemm256r.h"
-#include "gemm256p.h"
+#include "gemm_shared.h"
 #include "gemm256q.h"
 #include "gemm256t.h"
 
@@ -298,36 +295,29 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epi = epi;
     a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
-    static const int gm_env = getenv("ISTVT_GEMM_GM") ? atoi(getenv("ISTVT_GEMM_GM")) : 0;
-    a.gm = gm_env > 0 ? gm_env : 4;       // sweep at the model's shapes: 4 is best or neutral everywhere
+    a.gm = 4;             // sweep at the model's shapes: 4 row-panels per tile group is best or neutral everywhere
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + bk - 1) / bk) * bk;
     a.kper = kper;
     splitk = (K + kper - 1) / kper;
     a.a_vec = (((uintptr_t)A % 16) == 0 && (lda * esz) % 16 == 0) ? 1 : 0;
     a.b_vec = (((uintptr_t)B % 16) == 0 && (ldb * esz) % 16 == 0) ? 1 : 0;
-    // large bf16 problems: 256x256 DMA-staged kernel (NT for forward / dgrad-with-W^T, TN for wgrad)
+    // Large bf16 problems run on the two 256x256 LDS-DMA kernels: NT (forward, input gradient over the cached W^T) on
+    // the persistent gemm256q, TN (weight gradient, fp32 split-K slabs) on gemm256t.  Everything they do not take --
+    // float32, narrow outputs, misaligned operands, operands >= 2 GiB (32-bit buffer offsets), K < 32, atomic outputs --
+    // runs on the generic 128x128 kernel below, which handles every mode.
     const bool out16 = N % 8 == 0 && ldc % 8 == 0 && ((uintptr_t)C % 16) == 0 &&
                        (!residual || (ldr % 8 == 0 && ((uintptr_t)residual % 16) == 0)) &&
                        (!C2 || ((uintptr_t)C2 % 16) == 0) && (!bias || ((uintptr_t)bias % 16) == 0);
     if (dtype == DT_BF16 && a.a_vec && a.b_vec && out16 && M >= ISTVT_G256_MIN && N >= ISTVT_G256_MIN && a_kc == b_kc &&
         (a_kc ? (K % 8 == 0) : (M % 8 == 0 && N % 8 == 0))) {
         const int tiles = ((M + T256 - 1) / T256) * ((N + T256 - 1) / T256);
-        dim3 grid(tiles, 1, splitk), block(512);
-        a.flat_splits = 0;
-        static const int flat = getenv("ISTVT_WGRAD_FLAT") ? atoi(getenv("ISTVT_WGRAD_FLAT")) : 0;   // measured: no gain (profiles/README.md), off
-        if (flat && !a_kc && splitk >= 8 && out_mode == 3) {         // weight gradient: one reduction slice per XCD at a time
-            a.flat_splits = splitk;
-            grid = dim3(8 * tiles * ((splitk + 7) / 8), 1, 1);
-        }
-        static const int dbg = getenv("ISTVT_GEMM_DBG") ? atoi(getenv("ISTVT_GEMM_DBG")) : 0;
-        static const int ring = getenv("ISTVT_GEMM_RING") ? atoi(getenv("ISTVT_GEMM_RING")) : 1;
-        // measured at the model's shapes (same device, interleaved): the 4-slot ring is ~5 % faster for
-        // the k-contiguous case, the 2-stage kernel ~8 % faster for the transposed-operand case
-        static const int persist = getenv("ISTVT_GEMM_PERSIST") ? atoi(getenv("ISTVT_GEMM_PERSIST")) : 1;
-        const bool q_ok = (long)M * lda * 2 < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K >= 32;
-        const bool p_ok = out_mode == 0 && splitk == 1 && (K > 96 || q_ok) && (!bias || alpha == 1.0f) &&!(epi == EPI_GELU_BWD && residual) && !(epi == EPI_GELU_FWD && residual);
-        if (dbg == 0 && persist && a_kc && p_ok) {
+        const dim3 block(512);
+        const bool q_ok = a_kc && (long)M * lda * 2 < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K >= 32 &&
+                          out_mode == 0 && splitk == 1 && (!bias || alpha == 1.0f) && !(epi != EPI_NONE && residual);
+        const bool t_ok = !a_kc && out_mode == 3 && !bias && !residual && epi == EPI_NONE &&
+                          (long)K * lda * 2 < 0x7fffffffL && (long)K * ldb * 2 < 0x7fffffffL;
+        if (q_ok) {
             // persistent NT kernel: one workgroup per CU walks its tiles with the LDS ring kept full across tiles
             static int cus = 0;
             if (cus == 0) {
@@ -339,92 +329,57 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             // Balanced rounds: 666 tiles on 256 CUs are three rounds whichever way they are dealt; dealing them to 224
             // workgroups (3 tiles each) takes the same time and leaves 32 CUs free for the whole launch -- for the
             // weight-gradient GEMM running on the side stream -- instead of 102 CUs free for the last round only.
-            static const int balance = getenv("ISTVT_GEMM_BALANCE") ? atoi(getenv("ISTVT_GEMM_BALANCE")) : 1;
-            int G = tiles < cus ? tiles : cus;
-            if (balance && tiles > cus) {
-                const int rounds = (tiles + cus - 1) / cus;
-                const int g8 = (((tiles + rounds - 1) / rounds) + 7) & ~7;     // multiple of 8: blockIdx & 7 stays the XCD
-                if (g8 < G) G = g8;
-            }
-            static const int qk = getenv("ISTVT_GEMM_Q") ? atoi(getenv("ISTVT_GEMM_Q")) : 1;
+            auto balanced = [&](int ntiles) {
+                int G = ntiles < cus ? ntiles : cus;
+                if (ntiles > cus) {
+                    const int rounds = (ntiles + cus - 1) / cus;
+                    const int g8 = (((ntiles + rounds - 1) / rounds) + 7) & ~7;     // multiple of 8: blockIdx & 7 stays the XCD
+                    if (g8 < G) G = g8;
+                }
+                return G;
+            };
 #ifdef ISTVT_GEMM_DIAG
             static const int qdbg = getenv("ISTVT_GEMM_QDBG") ? atoi(getenv("ISTVT_GEMM_QDBG")) : 0;
             if (qdbg && epi == 0 && !residual) {
+                const int G = balanced(tiles);
                 switch (qdbg) {
                     case 1: hipLaunchKernelGGL((gemm256q_kernel<0, false, 1>), dim3(G), block, 0, stream, a); break;
                     case 2: hipLaunchKernelGGL((gemm256q_kernel<0, false, 2>), dim3(G), block, 0, stream, a); break;
-                    case 3: hipLaunchKernelGGL((gemm256q_kernel<0, false, 3>), dim3(G), block, 0, stream, a); break;
                     case 4: hipLaunchKernelGGL((gemm256q_kernel<0, false, 4>), dim3(G), block, 0, stream, a); break;
-                    case 5: hipLaunchKernelGGL((gemm256q_kernel<0, false, 5>), dim3(G), block, 0, stream, a); break;
-                    case 6: hipLaunchKernelGGL((gemm256q_kernel<0, false, 6>), dim3(G), block, 0, stream, a); break;
-                    case 7: hipLaunchKernelGGL((gemm256q_kernel<0, false, 7>), dim3(G), block, 0, stream, a); break;
-                    case 16: hipLaunchKernelGGL((gemm256q_kernel<0, false, 16>), dim3(G), block, 0, stream, a); break;
-                    case 32: hipLaunchKernelGGL((gemm256q_kernel<0, false, 32>), dim3(G), block, 0, stream, a); break;
-                    case 48: hipLaunchKernelGGL((gemm256q_kernel<0, false, 48>), dim3(G), block, 0, stream, a); break;
-                    case 80: hipLaunchKernelGGL((gemm256q_kernel<0, false, 80>), dim3(G), block, 0, stream, a); break;
                     default: hipLaunchKernelGGL((gemm256q_kernel<0, false, 8>), dim3(G), block, 0, stream, a); break;
                 }
                 return istvt_check_launch();
             }
 #endif
-            if (qk && q_ok) {       // 64-deep K tiles in 128-byte-row units, two wave groups in ping-pong (gemm256q.h)
-                // 224-row tiles (gemm256q.h) fill the rounds better at the model's shapes (cost = rounds x tile height),
-                // but a tile's time does not shrink with its row count -- the load slot, not the MFMA count, sets the K
-                // loop, and the epilogue is per tile: measured at C2, 254 x 3 tiles of 224 rows against 222 x 3 of 256:
-                // N=728/K=2912 +2 %, N=512/K=728 +2.5 %, the GELU epilogue GEMMs -5..-8 %, the step +0.5 ms.  Off by
-                // default: ISTVT_GEMM_TM=224 forces it, =-1 picks by rounds x height.
-                static const int tm_env = getenv("ISTVT_GEMM_TM") ? atoi(getenv("ISTVT_GEMM_TM")) : 0;
-                const int tiles224 = ((M + 223) / 224) * ((N + T256 - 1) / T256);
-                const long cost256 = (long)((tiles + cus - 1) / cus) * 256, cost224 = (long)((tiles224 + cus - 1) / cus) * 224;
-                const bool use224 = tm_env == 224 || (tm_env == -1 && cost224 < cost256);
-                if (use224) {
-                    int G2 = tiles224 < cus ? tiles224 : cus;
-                    if (balance && tiles224 > cus) {
-                        const int rounds = (tiles224 + cus - 1) / cus;
-                        const int g8 = (((tiles224 + rounds - 1) / rounds) + 7) & ~7;
-                        if (g8 < G2) G2 = g8;
-                    }
-                    if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false, 0, 224>), dim3(G2), block, 0, stream, a);
-                    else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 224>), dim3(G2), block, 0, stream, a);
-                    else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true, 0, 224>), dim3(G2), block, 0, stream, a);
-                    else hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 224>), dim3(G2), block, 0, stream, a);
-                    return istvt_check_launch();
-                }
-                if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
-                else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
-                else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), dim3(G), block, 0, stream, a);
-                else hipLaunchKernelGGL((gemm256q_kernel<0, false>), dim3(G), block, 0, stream, a);
-            } else if (K <= 96) {
-                hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
-            } else if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_FWD, false>), dim3(G), block, 0, stream, a);
-            else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256p_kernel<EPI_GELU_BWD, false>), dim3(G), block, 0, stream, a);
-            else if (residual) hipLaunchKernelGGL((gemm256p_kernel<0, true>), dim3(G), block, 0, stream, a);
-            else hipLaunchKernelGGL((gemm256p_kernel<0, false>), dim3(G), block, 0, stream, a);
-        } else if (dbg == 0 && !a_kc && out_mode == 3 && !bias && !residual && epi == 0 && !a.flat_splits &&
-                   (long)K * lda * 2 < 0x7fffffffL && (long)K * ldb * 2 < 0x7fffffffL &&
-                   (getenv("ISTVT_GEMM_T") ? atoi(getenv("ISTVT_GEMM_T")) : 1)) {
-            // weight gradient: unit / ping-pong structure with transposing fragment reads (gemm256t.h)
-            hipLaunchKernelGGL(gemm256t_kernel, grid, block, 0, stream, a);
-        } else if (dbg == 0 && ring >= 1 && a_kc) {
-            if (a_kc) hipLaunchKernelGGL((gemm256r_kernel<false>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((gemm256r_kernel<true>), grid, block, 0, stream, a);
-        } else if (dbg == 0) {
-            if (a_kc) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, stream, a);
+            // 224-row tiles (gemm256q.h) fill the rounds better at the model's shapes (cost = rounds x tile height),
+            // but a tile's time does not shrink with its row count -- the load slot, not the MFMA count, sets the K
+            // loop, and the epilogue is per tile: measured at C2, 254 x 3 tiles of 224 rows against 222 x 3 of 256:
+            // N=728/K=2912 +2 %, N=512/K=728 +2.5 %, the GELU epilogue GEMMs -5..-8 %, the step +0.5 ms.  Off by
+            // default: ISTVT_GEMM_TM=224 forces it (tests/test_model_gpu.py runs the GEMM checks that way), =-1 picks
+            // by rounds x height.
+            static const int tm_env = getenv("ISTVT_GEMM_TM") ? atoi(getenv("ISTVT_GEMM_TM")) : 0;
+            const int tiles224 = ((M + 223) / 224) * ((N + T256 - 1) / T256);
+            const long cost256 = (long)((tiles + cus - 1) / cus) * 256, cost224 = (long)((tiles224 + cus - 1) / cus) * 224;
+            if (tm_env == 224 || (tm_env == -1 && cost224 < cost256)) {
+                const dim3 grid(balanced(tiles224));
+                if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false, 0, 224>), grid, block, 0, stream, a);
+                else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 224>), grid, block, 0, stream, a);
+                else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true, 0, 224>), grid, block, 0, stream, a);
+                else hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 224>), grid, block, 0, stream, a);
+                return istvt_check_launch();
+            }
+            const dim3 grid(balanced(tiles));
+            if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), grid, block, 0, stream, a);
+            else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), grid, block, 0, stream, a);
+            else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((gemm256q_kernel<0, false>), grid, block, 0, stream, a);
+            return istvt_check_launch();
         }
-#ifdef ISTVT_GEMM_DIAG
-        else if (dbg == 16) hipLaunchKernelGGL((gemm256r_kernel<false, 6>), grid, block, 0, stream, a);
-        else if (dbg == 12) hipLaunchKernelGGL((gemm256r_kernel<false, 2>), grid, block, 0, stream, a);
-        else if (dbg == 14) hipLaunchKernelGGL((gemm256r_kernel<false, 4>), grid, block, 0, stream, a);
-        else if (dbg == 1) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, 0, stream, a);
-        else if (dbg == 2) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, 0, stream, a);
-        else if (dbg == 4) hipLaunchKernelGGL((gemm256_kernel<false, 4>), grid, block, 0, stream, a);
-        else if (dbg == 6) hipLaunchKernelGGL((gemm256_kernel<false, 6>), grid, block, 0, stream, a);
-        else if (dbg == 3) hipLaunchKernelGGL((gemm256_kernel<false, 3>), grid, block, 0, stream, a);
-        else if (dbg == 5) hipLaunchKernelGGL((gemm256_kernel<false, 5>), grid, block, 0, stream, a);
-#endif
-        else return ISTVT_ERR_SHAPE;
-        return istvt_check_launch();
+        if (t_ok) {
+            // weight gradient: unit / ping-pong structure with transposing fragment reads (gemm256t.h)
+            hipLaunchKernelGGL(gemm256t_kernel, dim3(tiles, 1, splitk), block, 0, stream, a);
+            return istvt_check_launch();
+        }
     }
     DISPATCH_DTYPE(dtype, return launch_gemm<T>(a, a_kc, b_kc, splitk, stream));
     return ISTVT_OK;

@@ -4,7 +4,7 @@
 // Why (measured with tools/dma_probe.hip on MI355X, one workgroup per CU streaming the FF1 panels into LDS,
 // no MFMA, no LDS reads):
 //      row piece / row stride            TB/s chip-wide
-//      64 B  (32-deep step) / 1456 B         10.4        <- gemm256r / gemm256p at K = 728
+//      64 B  (32-deep step) / 1456 B         10.4        <- the earlier 32-deep ring kernels at K = 728
 //      64 B                 / 1536 B         15.0
 //      128 B (64-deep)      / 1456 B         14.6
 //      128 B                / 1536 B         22.5
@@ -63,7 +63,9 @@ __device__ __forceinline__ void slot_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// EPI / SIDE as in gemm256p_kernel.  Requires 16-byte aligned rows and operands
+// EPI: 0 plain, 1 GELU forward (C = u, C2 = gelu(u)), 2 GELU backward (C = acc * gelu'(C2)).  SIDE: EPI 0 adds the
+// residual rows.  Output is bf16; bias optional at run time (needs alpha == 1: it is added to the accumulators).
+// Requires 16-byte aligned rows and operands
 // smaller than 2 GiB (32-bit buffer offsets).
 // DBG (diagnostic builds only, -DISTVT_GEMM_DIAG + ISTVT_GEMM_QDBG=n): 1 = no DMA inside the K loop, 2 = no MFMA,
 // 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2.
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         if (wm == 0) slot_barrier();           // re-align the two groups: both run the epilogue together
         if (DBG & 8) t_stamp[1] = __builtin_amdgcn_s_memtime();
 
-        // ---- epilogue: wave-local, 8 passes of 16 rows through this wave's slab (as gemm256p_kernel) ----
+        // ---- epilogue: wave-local, 8 passes of 16 rows through this wave's slab ----
         const long c_org = ((long)bm0 * ldc + bn0) * 2;
         const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr((char*)p.C + c_org), 0, WINDOW, RSRC_FLAGS);
         const __amdgpu_buffer_rsrc_t c2_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                     __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, 0);
                 }
             }
-            // STORE-DATA HAZARD, see gemm256p.h
+            // STORE-DATA HAZARD, see gemm_shared.h
             if (EPI == EPI_GELU_FWD)
                 asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1]), "+v"(held2[0]), "+v"(held2[1])::"memory");
             else

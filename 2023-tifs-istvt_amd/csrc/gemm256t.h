@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
             __builtin_amdgcn_raw_buffer_store_b128(held[2 * it], c_rs, voff, rb * ldc * 4, 0);
             __builtin_amdgcn_raw_buffer_store_b128(held[2 * it + 1], c_rs, voff + 16, rb * ldc * 4, 0);
         }
-        // STORE-DATA HAZARD, see gemm256p.h: the data registers stay allocated and padded until the stores have read them
+        // STORE-DATA HAZARD, see gemm_shared.h: the data registers stay allocated and padded until the stores have read them
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1]), "+v"(held[2]), "+v"(held[3])::"memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();

@@ -75,6 +75,10 @@ class GradBucket:
                 off += n
 
     def zero(self):
+        # weight gradients of a backward pass that aborted may still be queued on the side stream: they must land
+        # before the zero fill, not after it
+        from . import functional as Fn
+        Fn.flush_stale_joins()
         self.flat.zero_()
 
     def enable_early_all_reduce(self, first_param: int, group=None):
