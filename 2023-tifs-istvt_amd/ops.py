@@ -188,27 +188,21 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
     big = (A.dtype == torch.bfloat16 and bool(a_kc) == bool(b_kc) and M >= G256_MIN and N >= G256_MIN and N % 8 == 0
            and lda % 8 == 0 and ldb % 8 == 0 and ldc % 8 == 0 and (K % 8 == 0 if a_kc else M % 8 == 0))
     if big:
-        q_ok = M * lda * 2 < 0x7fffffff and N * ldb * 2 < 0x7fffffff and K >= 32
-        persistent = (a_kc and out_mode == 0 and splitk == 1 and (K > 96 or q_ok) and (bias is None or alpha == 1.0)
-                      and not (epi != 0 and residual is not None) and os.environ.get('ISTVT_GEMM_PERSIST', '1') != '0')
-        if persistent:
+        q_ok = (a_kc and M * lda * 2 < 0x7fffffff and N * ldb * 2 < 0x7fffffff and K >= 32 and out_mode == 0 and splitk == 1
+                and (bias is None or alpha == 1.0) and not (epi != 0 and residual is not None))
+        if q_ok:
             side = 'true' if (epi == 0 and residual is not None) else 'false'
-            if q_ok and os.environ.get('ISTVT_GEMM_Q', '1') != '0':
-                # row tile height as gemm.hip picks it: 256 unless ISTVT_GEMM_TM=224 (force) / -1 (rounds x height)
-                cus = _cu_count(A.device)
-                t256 = -(-M // 256) * -(-N // 256)
-                t224 = -(-M // 224) * -(-N // 256)
-                tm_env = int(os.environ.get('ISTVT_GEMM_TM', '0'))
-                use224 = tm_env == 224 or (tm_env == -1 and -(-t224 // cus) * 224 < -(-t256 // cus) * 256)
-                return 'gemm256q_kernel<%d, %s, 0, %d>' % (epi, side, 224 if use224 else 256)
-            if K <= 96:
-                return 'gemm256r_kernel<false, 0>'
-            return 'gemm256p_kernel<%d, %s>' % (epi, side)
-        if a_kc:
-            return 'gemm256r_kernel<false, 0>'
-        t_ok = (out_mode == 3 and bias is None and residual is None and epi == 0 and K * lda * 2 < 0x7fffffff
-                and K * ldb * 2 < 0x7fffffff and os.environ.get('ISTVT_GEMM_T', '1') != '0')
-        return 'gemm256t_kernel' if t_ok else 'gemm256_kernel<true, 0>'
+            # row tile height as gemm.hip picks it: 256 unless ISTVT_GEMM_TM=224 (force) / -1 (rounds x height)
+            cus = _cu_count(A.device)
+            t256 = -(-M // 256) * -(-N // 256)
+            t224 = -(-M // 224) * -(-N // 256)
+            tm_env = int(os.environ.get('ISTVT_GEMM_TM', '0'))
+            use224 = tm_env == 224 or (tm_env == -1 and -(-t224 // cus) * 224 < -(-t256 // cus) * 256)
+            return 'gemm256q_kernel<%d, %s, 0, %d>' % (epi, side, 224 if use224 else 256)
+        t_ok = (not a_kc and out_mode == 3 and bias is None and residual is None and epi == 0 and K * lda * 2 < 0x7fffffff
+                and K * ldb * 2 < 0x7fffffff)
+        if t_ok:
+            return 'gemm256t_kernel'
     t = '__bf16' if A.dtype == torch.bfloat16 else 'float'
     return 'gemm_kernel<%s, %s, %s>' % (t, str(bool(a_kc)).lower(), str(bool(b_kc)).lower())
 

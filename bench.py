@@ -62,9 +62,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(frames, size, depth, clips=8):
-    """oracle (kind "port"): one fwd+bwd of a batch of `clips` clips of the benchmark geometry on the host cores
-    (bounded sample: ~1.6 s per clip on the GPU box's host -> ~10-15 s)."""
+def cpu_baseline(frames, size, depth, clips=2, reps=3):
+    """oracle (kind "port"): fwd+bwd of a batch of `clips` clips of the benchmark geometry on the host cores, one
+    warm-up + `reps` timed repetitions, median; bounded sample: ~1.6 s per clip on the GPU box's host ->
+    (1 + 3) x 2 clips ~ 13 s."""
     from oracle import istvt_ref as R
     # torch's intra-op pool stops scaling (and then collapses) far below the 256 hardware threads of
     # the GPU box's host on this small problem: 256 threads took 209 s for the one clip, so cap at 32
@@ -73,16 +74,31 @@ def cpu_baseline(frames, size, depth, clips=8):
     grid = R.stem_out_side(size)
     shapes = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
     shapes.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(frames, grid, depth=depth).items()})
-    p = R.with_grad(R.random_params(shapes, seed=0))
+    p0 = R.random_params(shapes, seed=0)
     x = torch.randn((clips, frames, 3, size, size), generator=torch.Generator().manual_seed(0))
     labels = torch.ones(clips)
-    t0 = time.perf_counter()
-    logits = R.xception_vidtr_forward(p, x, depth=depth)
-    R.bce_with_logits(logits, labels).backward()
-    dt = time.perf_counter() - t0
+    times = []
+    for rep in range(reps + 1):
+        p = R.with_grad(p0)
+        t0 = time.perf_counter()
+        logits = R.xception_vidtr_forward(p, x, depth=depth)
+        R.bce_with_logits(logits, labels).backward()
+        if rep > 0:
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'sample': 'one batch of %d clips (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads, %.1f s'
-                      % (clips, frames, size, size, depth, torch.get_num_threads(), dt)}
+            'sample': 'batch of %d clips (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads: 1 warm-up + '
+                      '%d repetitions, median %.1f s (all: %s)' % (clips, frames, size, size, depth, torch.get_num_threads(), reps,
+                                                                 dt, ', '.join('%.1f' % t for t in times))}
+
+
+def pmc_summary_path():
+    """newest committed PMC summary (profiles/pmc/rNN_pmc_whole_step_summary.json)"""
+    d = os.path.join(ROOT, 'profiles', 'pmc')
+    if not os.path.isdir(d):
+        return None
+    names = sorted(f for f in os.listdir(d) if f.endswith('_pmc_whole_step_summary.json'))
+    return os.path.join(d, names[-1]) if names else None
 
 
 def main():
@@ -177,10 +193,15 @@ def main():
     t_enq = (marks[min(1, len(marks) - 1)] - t0) / min(2, len(marks))
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time for the K steps (the first N > 1 run on real hardware should diagnose itself: a slow rank,
+        # a slow link or the collective show up here), then the MAX over ranks as the job's time
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [round(float(t.item()) / a.steps * 1e3, 3) for t in allt]
+        elapsed = max(float(t.item()) for t in allt)
     loss_val = float(loss.item())
 
     # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
@@ -241,14 +262,14 @@ def main():
                                                'launches': v[2]} for k, v in by.items()}}}
         # HBM traffic per launch is not measurable from inside the process: it comes from the committed PMC
         # passes over this same command (profiles/pmc/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE)
-        pmc = os.path.join(ROOT, 'profiles', 'pmc', 'r01_pmc_whole_step_summary.json')
+        pmc = pmc_summary_path()
         is_c2 = (a.batch, a.frames, a.size, a.depth, a.dtype) == (32, 8, 224, 12, 'bf16')
-        if is_c2 and os.path.exists(pmc):
+        if is_c2 and pmc:
             table = json.load(open(pmc))
             rec = table.get('void ' + dom + '(GemmArgs)') or table.get(dom + '(GemmArgs)') or table.get('void ' + dom)
             if rec and 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
                 roof['traffic'] = round((2.0 * rec['FETCH_SIZE']['avg_KB'] + rec['WRITE_SIZE']['avg_KB']) * 1024)
-                roof['traffic_unit'] = 'bytes/launch (rocprofv3 --pmc, profiles/pmc/)'
+                roof['traffic_unit'] = 'bytes/launch (rocprofv3 --pmc, profiles/pmc/%s)' % os.path.basename(pmc)
 
     if rank == 0:
         clips = world * a.batch * a.steps
@@ -276,6 +297,11 @@ def main():
         # bound.  (Replaying the step as one captured HIP graph was tried: hipGraphLaunch of the 1500-node graph costs
         # the host 35 ms per replay on this ROCm, no better than the eager loop.)
         out['host_enqueue_ms_per_step'] = round(t_enq * 1e3, 3)
+        if world > 1:
+            out['distributed'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                  'per_rank_ms_per_step': per_rank,
+                                  'grad_bucket_MB': round(bucket.numel * 4 / 2**20, 1),
+                                  'scale_folded_into_optimizer': bool(bucket.defer_scale)}
         ms = torch.cuda.memory_stats(dev)
         out['allocator'] = {'reserved_GB': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),
                             'device_allocs': ms.get('num_device_alloc', 0), 'device_frees': ms.get('num_device_free', 0),
