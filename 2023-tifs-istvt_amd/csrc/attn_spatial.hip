@@ -89,6 +89,29 @@ __device__ __forceinline__ void stage_commit(T* img, const StageRegs<T, DH, NTHR
     }
 }
 
+// RES mode staging: rows [0, P) of two matrices into NCH x 128-row images each, every global load issued before the
+// first LDS store (stage_img's load -> store pairs made the two matrices two dependent memory round trips)
+template <typename T, int DH, int NTHR, int NCH>
+__device__ __forceinline__ void stage_all2(T* imgA, const T* __restrict__ srcA, long ldA, T* imgB, const T* __restrict__ srcB,
+                                           long ldB, int P, int tid) {
+    constexpr int LDI = DH + IPAD;
+    StageRegs<T, DH, NTHR> ra[NCH], rb[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch * CHUNK < P) {
+            stage_fetch(ra[ch], srcA, ldA, ch * CHUNK, P, tid);
+            stage_fetch(rb[ch], srcB, ldB, ch * CHUNK, P, tid);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch * CHUNK < P) {
+            stage_commit(imgA + ch * CHUNK * LDI, ra[ch], tid);
+            stage_commit(imgB + ch * CHUNK * LDI, rb[ch], tid);
+        }
+    }
+}
+
 // fragment (8 consecutive d) of one row of a global matrix, zero if the row is out of range
 template <typename T>
 __device__ __forceinline__ typename Mma<T>::frag row_frag(const T* __restrict__ src, long ld, int row, int nrows,
@@ -124,26 +147,27 @@ __device__ __forceinline__ long to_fp8(const f32frag& f) { return pack_fp8(f.v);
 __device__ __forceinline__ void mma8(f32x4& c, long a, long b) { c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
 constexpr float P8_SCALE = 256.f;          // probabilities (<= 1) are scaled into e4m3's normal range before conversion
 
-__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same r)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
+__device__ __forceinline__ float group_max(float v) { return xgroup_max(v); }      // over the 4 lane groups (same r)
+__device__ __forceinline__ float group_sum(float v) { return xgroup_sum(v); }
 
 // ------------------------------------------------------------------------------------------
 // U = query tiles (of 16) per wavefront, 128 / (16 U) wavefronts per workgroup.  U = 1 (8 wavefronts) halves the
 // registers of a wavefront: 4 instead of 2 wavefronts per SIMD, whose softmax (VALU) and MFMA phases then overlap and
 // whose staging latencies hide each other (the kernel is bound by neither pipe: it waits).
-template <typename T, int DH, int U, bool FP8 = false>
+// RES (resident keys, P <= RES_CHUNKS * 128): ONE workgroup per (frame, head) stages every key / value row once and walks
+// the query blocks itself, instead of ceil(P / 128) workgroups that each stage all keys (P = 197: two workgroups, K and
+// V fetched twice, 1.57x the algorithmic bytes by the PMC pass; the kernel is bound by that traffic).  After the one
+// barrier behind the staging the wavefronts run independently: no chunk barriers, no re-staging.
+constexpr int RES_CHUNKS = 2;
+
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         float* __restrict__ lse, int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
-    __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
+    constexpr int NIMG = RES ? RES_CHUNKS : 1;
+    __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
     T* Kimg = smem;
-    T* Vimg = smem + CHUNK * LDI;
+    T* Vimg = smem + NIMG * CHUNK * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
@@ -152,9 +176,29 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
     const T* qp = base + h * DH;
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
-    const int q0 = blockIdx.x * 128 + wave * 16 * U;
-    const bool active = q0 < P;
     const float c = scale * LOG2E;
+    constexpr int NBLK = RES ? RES_CHUNKS : 1;
+    // the query rows of EVERY block this wavefront will own are requested first: in RES mode their latency then hides
+    // behind the staging (a global-memory round trip under load is ~2 us: one per block was a third of a wavefront's life)
+    typename Mma<T>::frag qf_pre[NBLK][U][KS];
+#pragma unroll
+    for (int qi = 0; qi < NBLK; ++qi)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf_pre[qi][u][ks] = row_frag<T>(qp, ld, (RES ? qi : (int)blockIdx.x) * 128 + wave * 16 * U + 16 * u + r, P,
+                                                32 * ks + 8 * g);
+    if constexpr (RES) {
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid);
+        __syncthreads();
+    }
+#pragma unroll
+  for (int qi = 0; qi < NBLK; ++qi) {
+    const int qblk = RES ? qi : (int)blockIdx.x;
+    const int q0 = qblk * 128 + wave * 16 * U;
+    const bool active = q0 < P;
+    if (RES && !active) break;                       // wave-uniform; nothing below synchronises in RES mode
 
     typename Mma<T>::frag qf[U][KS];
     long q8[U][KS];
@@ -162,7 +206,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[u][ks] = row_frag<T>(qp, ld, q0 + 16 * u + r, P, 32 * ks + 8 * g);
+            qf[u][ks] = qf_pre[qi][u][ks];
             if constexpr (FP8) q8[u][ks] = to_fp8(qf[u][ks]);
         }
 
@@ -181,6 +225,8 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
     // and the scale rides in the exponent's FMA.
     auto chunk = [&](const int c0, auto tail_c) {
         constexpr bool TAIL = decltype(tail_c)::value;
+        const T* const Kimg_c = RES ? Kimg + (c0 / CHUNK) * CHUNK * LDI : Kimg;
+        const T* const Vimg_c = RES ? Vimg + (c0 / CHUNK) * CHUNK * LDI : Vimg;
         f32x4 s[NT][U];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -189,7 +235,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
             if (!TAIL || c0 + 16 * t < P) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    typename Mma<T>::frag kf = frag_load(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag kf = frag_load(Kimg_c + (16 * t + r) * LDI + 32 * ks + 8 * g);
                     if constexpr (FP8) {
                         const long k8 = to_fp8(kf);
 #pragma unroll
@@ -250,7 +296,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     typename Mma<T>::frag vf =
-                        frag_load_tr(Vimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                        frag_load_tr(Vimg_c, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
                     if constexpr (FP8) {
                         const long v8 = to_fp8(vf);
 #pragma unroll
@@ -263,23 +309,30 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
             }
         }
     };
-    StageRegs<T, DH, 512 / U> kreg, vreg;
-    stage_fetch(kreg, kp, ld, 0, P, tid);
-    stage_fetch(vreg, vp, ld, 0, P, tid);
-    for (int c0 = 0; c0 < P; c0 += CHUNK) {
-        if (c0) __syncthreads();
-        stage_commit(Kimg, kreg, tid);
-        stage_commit(Vimg, vreg, tid);
-        __syncthreads();
-        if (c0 + CHUNK < P) {                       // next chunk's rows: in flight under this chunk's MFMAs
-            stage_fetch(kreg, kp, ld, c0 + CHUNK, P, tid);
-            stage_fetch(vreg, vp, ld, c0 + CHUNK, P, tid);
+    if constexpr (RES) {
+        for (int c0 = 0; c0 < P; c0 += CHUNK) {
+            if (c0 + CHUNK > P) chunk(c0, std::true_type{});
+            else chunk(c0, std::false_type{});
         }
-        if (!active) continue;
-        if (c0 + CHUNK > P) chunk(c0, std::true_type{});
-        else chunk(c0, std::false_type{});
+    } else {
+        StageRegs<T, DH, 512 / U> kreg, vreg;
+        stage_fetch(kreg, kp, ld, 0, P, tid);
+        stage_fetch(vreg, vp, ld, 0, P, tid);
+        for (int c0 = 0; c0 < P; c0 += CHUNK) {
+            if (c0) __syncthreads();
+            stage_commit(Kimg, kreg, tid);
+            stage_commit(Vimg, vreg, tid);
+            __syncthreads();
+            if (c0 + CHUNK < P) {                       // next chunk's rows: in flight under this chunk's MFMAs
+                stage_fetch(kreg, kp, ld, c0 + CHUNK, P, tid);
+                stage_fetch(vreg, vp, ld, c0 + CHUNK, P, tid);
+            }
+            if (!active) continue;
+            if (c0 + CHUNK > P) chunk(c0, std::true_type{});
+            else chunk(c0, std::false_type{});
+        }
+        if (!active) return;
     }
-    if (!active) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int q = q0 + 16 * u + r;
@@ -300,19 +353,21 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
             *st = make_float2(m_run[u], inv);
         }
     }
+  }   // query blocks
 }
 
 // ------------------------------------------------------------------------------------------
 // backward part 1: delta = rowsum(dO o O), dQ
-template <typename T, int DH, int U, bool FP8 = false>
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv, int P,
                                                            int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
-    __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
+    constexpr int NIMG = RES ? RES_CHUNKS : 1;
+    __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
     T* Kimg = smem;
-    T* Vimg = smem + CHUNK * LDI;
+    T* Vimg = smem + NIMG * CHUNK * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
@@ -323,9 +378,34 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
     const T* vp = base + 2 * inner + h * DH;
     const T* op = out + (long)bf * P * inner + h * DH;
     const T* dop = dout + (long)bf * P * inner + h * DH;
-    const int q0 = blockIdx.x * 128 + wave * 16 * U;
-    const bool active = q0 < P;
     const float c = scale * LOG2E;
+    constexpr int NBLK = RES ? RES_CHUNKS : 1;
+    // rows of every query block this wavefront will own, requested before the staging (see sattn_fwd_kernel)
+    typename Mma<T>::frag qf_pre[NBLK][U][KS], dof_pre[NBLK][U][KS], of_pre[NBLK][U][KS];
+    float2 st_pre[NBLK][U];
+#pragma unroll
+    for (int qi = 0; qi < NBLK; ++qi)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = (RES ? qi : (int)blockIdx.x) * 128 + wave * 16 * U + 16 * u + r;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qf_pre[qi][u][ks] = row_frag<T>(qp, ld, q, P, 32 * ks + 8 * g);
+                dof_pre[qi][u][ks] = row_frag<T>(dop, inner, q, P, 32 * ks + 8 * g);
+                of_pre[qi][u][ks] = row_frag<T>(op, inner, q, P, 32 * ks + 8 * g);
+            }
+            st_pre[qi][u] = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
+        }
+    if constexpr (RES) {                               // every key / value row staged once (see sattn_fwd_kernel)
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid);
+        __syncthreads();
+    }
+#pragma unroll
+  for (int qi = 0; qi < NBLK; ++qi) {
+    const int qblk = RES ? qi : (int)blockIdx.x;
+    const int q0 = qblk * 128 + wave * 16 * U;
+    const bool active = q0 < P;
+    if (RES && !active) break;
 
     typename Mma<T>::frag qf[U][KS], dof[U][KS];
     long q8[U][KS];
@@ -336,19 +416,14 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
         float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[u][ks] = row_frag<T>(qp, ld, q, P, 32 * ks + 8 * g);
+            qf[u][ks] = qf_pre[qi][u][ks];
             if constexpr (FP8) q8[u][ks] = to_fp8(qf[u][ks]);        // S is recomputed exactly as the forward computed it
-            dof[u][ks] = row_frag<T>(dop, inner, q, P, 32 * ks + 8 * g);
-            if (q < P) {
-                float a[8], b[8];
-                load8(dop + (long)q * inner + 32 * ks + 8 * g, a);
-                load8(op + (long)q * inner + 32 * ks + 8 * g, b);
+            dof[u][ks] = dof_pre[qi][u][ks];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) part += a[i] * b[i];
-            }
+            for (int i = 0; i < 8; ++i) part += Mma<T>::get(dof[u][ks], i) * Mma<T>::get(of_pre[qi][u][ks], i);   // rows past P are zero
         }
         dl[u] = group_sum(part);
-        const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
+        const float2 st = st_pre[qi][u];
         // exponent offset with 1/rowsum folded in: p = exp2(s c - (max - log2(1/sum))); rows past P have 1/sum = 0 ->
         // offset +inf -> p = 0
         lq[u] = st.x - __builtin_amdgcn_logf(st.y); li[u] = st.y;
@@ -362,18 +437,24 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
         for (int u = 0; u < U; ++u) dq[dt][u] = f32x4{0, 0, 0, 0};
 
     StageRegs<T, DH, 512 / U> kreg, vreg;
-    stage_fetch(kreg, kp, ld, 0, P, tid);
-    stage_fetch(vreg, vp, ld, 0, P, tid);
+    if constexpr (!RES) {
+        stage_fetch(kreg, kp, ld, 0, P, tid);
+        stage_fetch(vreg, vp, ld, 0, P, tid);
+    }
     for (int c0 = 0; c0 < P; c0 += CHUNK) {
-        if (c0) __syncthreads();
-        stage_commit(Kimg, kreg, tid);
-        stage_commit(Vimg, vreg, tid);
-        __syncthreads();
-        if (c0 + CHUNK < P) {
-            stage_fetch(kreg, kp, ld, c0 + CHUNK, P, tid);
-            stage_fetch(vreg, vp, ld, c0 + CHUNK, P, tid);
+        if constexpr (!RES) {
+            if (c0) __syncthreads();
+            stage_commit(Kimg, kreg, tid);
+            stage_commit(Vimg, vreg, tid);
+            __syncthreads();
+            if (c0 + CHUNK < P) {
+                stage_fetch(kreg, kp, ld, c0 + CHUNK, P, tid);
+                stage_fetch(vreg, vp, ld, c0 + CHUNK, P, tid);
+            }
+            if (!active) continue;
         }
-        if (!active) continue;
+        const T* const Kimg_c = RES ? Kimg + (c0 / CHUNK) * CHUNK * LDI : Kimg;
+        const T* const Vimg_c = RES ? Vimg + (c0 / CHUNK) * CHUNK * LDI : Vimg;
         const bool tail = c0 + CHUNK > P;
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
@@ -386,8 +467,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
                 const int krow = 32 * ss + 16 * tt + r;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    typename Mma<T>::frag kf = frag_load(Kimg + krow * LDI + 32 * ks + 8 * g);
-                    typename Mma<T>::frag vf = frag_load(Vimg + krow * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag kf = frag_load(Kimg_c + krow * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag vf = frag_load(Vimg_c + krow * LDI + 32 * ks + 8 * g);
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if constexpr (FP8) mma8(s[tt][u], to_fp8(kf), q8[u][ks]);
@@ -409,7 +490,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
             for (int u = 0; u < U; ++u) dsf[u] = acc_frag<T>(s[0][u], s[1][u]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                typename Mma<T>::frag kt = frag_load_tr(Kimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                typename Mma<T>::frag kt = frag_load_tr(Kimg_c, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
 #pragma unroll
                 for (int u = 0; u < U; ++u) Mma<T>::mma(dq[dt][u], kt, dsf[u]);
             }
@@ -427,20 +508,22 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
             store4(dqp + 16 * dt + 4 * g, v);
         }
     }
+  }   // query blocks
 }
 
 // ------------------------------------------------------------------------------------------
 // backward part 2: dK, dV.  Wave owns 32 keys; queries stream through LDS.
-template <typename T, int DH, int U, bool FP8 = false>
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
                                                             int P, int heads, float scale) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
-    __shared__ __attribute__((aligned(16))) T smem[2 * CHUNK * LDI];
-    __shared__ __attribute__((aligned(16))) float stat[2][CHUNK];
+    constexpr int NIMG = RES ? RES_CHUNKS : 1;
+    __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
+    __shared__ __attribute__((aligned(16))) float stat_s[2][NIMG * CHUNK];
     T* Qimg = smem;
-    T* Dimg = smem + CHUNK * LDI;
+    T* Dimg = smem + NIMG * CHUNK * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
@@ -450,9 +533,35 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
     const T* dop = dout + (long)bf * P * inner + h * DH;
-    const int k0 = blockIdx.x * 128 + wave * 16 * U;
-    const bool active = k0 < P;
     const float c = scale * LOG2E;
+    constexpr int NBLK = RES ? RES_CHUNKS : 1;
+    // key / value rows of every block this wavefront will own, requested before the staging (see sattn_fwd_kernel)
+    typename Mma<T>::frag kf_pre[NBLK][U][KS], vf_pre[NBLK][U][KS];
+#pragma unroll
+    for (int ki = 0; ki < NBLK; ++ki)
+#pragma unroll
+        for (int kt = 0; kt < U; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int key = (RES ? ki : (int)blockIdx.x) * 128 + wave * 16 * U + 16 * kt + r;
+                kf_pre[ki][kt][ks] = row_frag<T>(kp, ld, key, P, 32 * ks + 8 * g);
+                vf_pre[ki][kt][ks] = row_frag<T>(vp, ld, key, P, 32 * ks + 8 * g);
+            }
+    if constexpr (RES) {                               // every query / dO row and its statistics staged once
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, (long)inner, P, tid);
+        for (int q = tid; q < NIMG * CHUNK; q += 512 / U) {
+            const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
+            stat_s[0][q] = st.x - __builtin_amdgcn_logf(st.y);       // exponent offset incl. log2(1/sum); +inf for padding
+            stat_s[1][q] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+  for (int ki = 0; ki < NBLK; ++ki) {
+    const int kblk = RES ? ki : (int)blockIdx.x;
+    const int k0 = kblk * 128 + wave * 16 * U;
+    const bool active = k0 < P;
+    if (RES && !active) break;
 
     typename Mma<T>::frag kf[U][KS], vf[U][KS];
     long k8[U][KS];
@@ -460,9 +569,9 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
     for (int kt = 0; kt < U; ++kt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[kt][ks] = row_frag<T>(kp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
+            kf[kt][ks] = kf_pre[ki][kt][ks];
             if constexpr (FP8) k8[kt][ks] = to_fp8(kf[kt][ks]);
-            vf[kt][ks] = row_frag<T>(vp, ld, k0 + 16 * kt + r, P, 32 * ks + 8 * g);
+            vf[kt][ks] = vf_pre[ki][kt][ks];
         }
     f32x4 dk[DT][U], dv[DT][U];
 #pragma unroll
@@ -483,18 +592,24 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
             dlreg = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
         }
     };
-    fetch(0);
+    if constexpr (!RES) fetch(0);
     for (int c0 = 0; c0 < P; c0 += CHUNK) {
-        if (c0) __syncthreads();
-        stage_commit(Qimg, qreg, tid);
-        stage_commit(Dimg, dreg, tid);
-        if (tid < CHUNK) {
-            stat[0][tid] = streg.x - __builtin_amdgcn_logf(streg.y);    // exponent offset incl. log2(1/sum); +inf for padding
-            stat[1][tid] = dlreg;
+        if constexpr (!RES) {
+            if (c0) __syncthreads();
+            stage_commit(Qimg, qreg, tid);
+            stage_commit(Dimg, dreg, tid);
+            if (tid < CHUNK) {
+                stat_s[0][tid] = streg.x - __builtin_amdgcn_logf(streg.y);    // exponent offset incl. log2(1/sum); +inf for padding
+                stat_s[1][tid] = dlreg;
+            }
+            __syncthreads();
+            if (c0 + CHUNK < P) fetch(c0 + CHUNK);
+            if (!active) continue;
         }
-        __syncthreads();
-        if (c0 + CHUNK < P) fetch(c0 + CHUNK);
-        if (!active) continue;
+        const T* const Qimg_c = RES ? Qimg + (c0 / CHUNK) * CHUNK * LDI : Qimg;
+        const T* const Dimg_c = RES ? Dimg + (c0 / CHUNK) * CHUNK * LDI : Dimg;
+        const float* const st0 = RES ? &stat_s[0][c0] : &stat_s[0][0];
+        const float* const st1 = RES ? &stat_s[1][c0] : &stat_s[1][0];
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss >= P) continue;
@@ -506,8 +621,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                 const int qrow = 32 * ss + 16 * tt + r;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    typename Mma<T>::frag qa = frag_load(Qimg + qrow * LDI + 32 * ks + 8 * g);
-                    typename Mma<T>::frag da = frag_load(Dimg + qrow * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag qa = frag_load(Qimg_c + qrow * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag da = frag_load(Dimg_c + qrow * LDI + 32 * ks + 8 * g);
 #pragma unroll
                     for (int kt = 0; kt < U; ++kt) {
                         if constexpr (FP8) mma8(s[tt][kt], to_fp8(qa), k8[kt][ks]);
@@ -516,8 +631,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                     }
                 }
                 const int qb = 32 * ss + 16 * tt + 4 * g;
-                const float4 l4 = *reinterpret_cast<const float4*>(&stat[0][qb]);
-                const float4 d4 = *reinterpret_cast<const float4*>(&stat[1][qb]);
+                const float4 l4 = *reinterpret_cast<const float4*>(st0 + qb);
+                const float4 d4 = *reinterpret_cast<const float4*>(st1 + qb);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int kt = 0; kt < U; ++kt)
@@ -533,8 +648,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
             for (int kt = 0; kt < U; ++kt) { pf[kt] = acc_frag<T>(s[0][kt], s[1][kt]); dsf[kt] = acc_frag<T>(dp[0][kt], dp[1][kt]); }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                typename Mma<T>::frag dot_ = frag_load_tr(Dimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
-                typename Mma<T>::frag qt_ = frag_load_tr(Qimg, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                typename Mma<T>::frag dot_ = frag_load_tr(Dimg_c, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
+                typename Mma<T>::frag qt_ = frag_load_tr(Qimg_c, LDI, 32 * ss + 4 * g, 32 * ss + 16 + 4 * g, 16 * dt, r);
 #pragma unroll
                 for (int kt = 0; kt < U; ++kt) {
                     Mma<T>::mma(dv[dt][kt], dot_, pf[kt]);
@@ -558,6 +673,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
             store4(dvp + 16 * dt + 4 * g, b);
         }
     }
+  }   // key blocks
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,9 +689,13 @@ extern "C" int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, in
                                       float scale, int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
-    static const int u1 = getenv("ISTVT_SATTN_U") ? atoi(getenv("ISTVT_SATTN_U")) : 1;
     // bf16: 8 wavefronts x 16 queries (more wavefronts per SIMD); fp32 keeps 4 x 32 (its LDS image fills the CU)
-    if (dtype == DT_BF16 && u1 == 1) {
+    if (dtype == DT_BF16) {
+        if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {      // one workgroup per (frame, head), keys resident (P = 197 at 224^2)
+            DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, false, true>), dim3(1, BF * heads), dim3(512), 0,
+                                               stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+            return istvt_check_launch();
+        }
         DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream,
                                            (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
         return istvt_check_launch();
@@ -592,8 +712,17 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, const void* out, const vo
                                       int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
-    static const int u1 = getenv("ISTVT_SATTN_U") ? atoi(getenv("ISTVT_SATTN_U")) : 1;
-    if (dtype == DT_BF16 && u1 == 1) {          // 8 wavefronts x 16 rows, see sattn_fwd_kernel
+    if (dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
+        const dim3 g1(1, BF * heads);
+        DISPATCH_DH(dh, {
+            hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
+                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+            hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, false, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
+                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+        });
+        return istvt_check_launch();
+    }
+    if (dtype == DT_BF16) {                     // 8 wavefronts x 16 rows, see sattn_fwd_kernel
         DISPATCH_DH(dh, {
             hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
                                (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
@@ -620,6 +749,11 @@ extern "C" int istvt_attn_spatial_fwd_fp8(const void* qkv, void* out, float* lse
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
+    if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
+        DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true, true>), dim3(1, BF * heads), dim3(512), 0,
+                                           stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+        return istvt_check_launch();
+    }
     DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream,
                                        (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
     return istvt_check_launch();
@@ -631,6 +765,16 @@ extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, const void* out, cons
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
+    if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
+        const dim3 g1(1, BF * heads);
+        DISPATCH_DH(dh, {
+            hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
+                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+            hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
+                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+        });
+        return istvt_check_launch();
+    }
     DISPATCH_DH(dh, {
         hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
                            (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);

@@ -67,14 +67,8 @@ __device__ __forceinline__ void mma_frames(f32x4& acc, const bf16_t* img, int ld
     if constexpr (NTL == 1) mma16(acc, tr4(img, ld, 4 * g, col16, r), acc_frag4(ya));
     else mma(acc, frag_load_tr(img, ld, 4 * g, 16 + 4 * g, col16, r), acc_frag(ya, yb));
 }
-__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same r)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
+__device__ __forceinline__ float group_max(float v) { return xgroup_max(v); }      // over the 4 lane groups (same r)
+__device__ __forceinline__ float group_sum(float v) { return xgroup_sum(v); }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();

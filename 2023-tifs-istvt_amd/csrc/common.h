@@ -126,6 +126,7 @@ template <> struct Mma<bf16_t> {
         return f;
     }
     static __device__ __forceinline__ void set(frag& f, int i, float v) { f[i] = (bf16_t)v; }
+    static __device__ __forceinline__ float get(const frag& f, int i) { return (float)f[i]; }
 };
 struct f32frag { float v[8]; };
 template <> struct Mma<float> {
@@ -141,7 +142,25 @@ template <> struct Mma<float> {
         return f;
     }
     static __device__ __forceinline__ void set(frag& f, int i, float v) { f.v[i] = v; }
+    static __device__ __forceinline__ float get(const frag& f, int i) { return f.v[i]; }
 };
+
+// Reductions over the four 16-lane groups of a wavefront (lanes r, r+16, r+32, r+48: the lanes that share an MFMA
+// accumulator column): two gfx950 half-swaps (v_permlane16_swap / v_permlane32_swap, vector-ALU latency) instead of two
+// ds_bpermute round trips through the LDS (~120 cycles each, on every softmax's critical path).  Swapping a value with
+// itself leaves {own half, other half} in the two results, so one op on them is the xor-16 / xor-32 butterfly step.
+__device__ __forceinline__ float xgroup_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xgroup_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 // fragment from 8 contiguous elements in LDS/global (16-byte aligned)
 __device__ __forceinline__ bf16x8 frag_load(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }

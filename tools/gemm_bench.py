@@ -10,7 +10,10 @@ import torch  # noqa: E402
 import istvt_pkg  # noqa: E402
 
 istvt_pkg.load()
-from istvt_amd import ops  # noqa: E402
+from istvt_amd import _lib, ops  # noqa: E402
+
+if os.environ.get('GB_LIB'):            # A/B a variant build of the library (same box, one process per variant)
+    _lib.LIB_PATH = os.path.abspath(os.environ['GB_LIB'])
 
 M = int(os.environ.get('GB_M', 56736))
 reps = int(os.environ.get('GB_REPS', 10))

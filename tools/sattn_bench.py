@@ -9,7 +9,10 @@ import torch  # noqa: E402
 import istvt_pkg  # noqa: E402
 
 istvt_pkg.load()
-from istvt_amd import ops  # noqa: E402
+from istvt_amd import _lib, ops  # noqa: E402
+
+if os.environ.get('GB_LIB'):            # A/B a variant build of the library (same box, one process per variant)
+    _lib.LIB_PATH = os.path.abspath(os.environ['GB_LIB'])
 
 dt = torch.bfloat16
 BF, heads, dh = 288, 8, 64
@@ -25,7 +28,7 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-for P in (64, 128, 197, 224, 256, 362):
+for P in [int(v) for v in os.environ.get('SA_PS', '64,128,197,224,256,362').split(',')]:
     qkv = torch.randn(BF * P, 1536, device='cuda').to(dt)
     do = torch.randn(BF * P, 512, device='cuda').to(dt)
     out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh)
