@@ -779,3 +779,4 @@ def all_checks():  # noqa: F811
     out.append(('attn_temporal_production_C4', lambda: attn_temporal_production(16, 17, 197, 8, 64, 128)))
     out.append(('stem_convdense_many_chunks_bf16', conv_dense_many_chunks))
     return out
+
