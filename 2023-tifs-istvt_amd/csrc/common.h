@@ -27,6 +27,10 @@ enum { DT_F32 = 0, DT_BF16 = 1 };
 
 #define WAVE 64
 
+// per-channel statistics accumulators are double[ISTVT_STAT_REPLICAS][2][C] (see stem.hip); producers add into replica
+// (workgroup % ISTVT_STAT_REPLICAS)
+constexpr int ISTVT_STAT_REPLICAS = 32;
+
 static inline int istvt_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ISTVT_OK : -(1000 + (int)e);

@@ -34,6 +34,8 @@ struct GemmArgs {
     float alpha;
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
     int gm;               // gemm256q: row-panels per tile group (L2 locality of the tile walk)
+    double* st_sum;       // gemm256q<.., STATS>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
+    double* st_sumsq;     //   (double[R][2][N] accumulators of stem.hip; train-mode BatchNorm statistics of a 1x1 conv)
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -283,7 +285,8 @@ static int launch_gemm(const GemmArgs& a, int a_kc, int b_kc, int splitk, hipStr
 
 extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc,
                           int M, int N, int K, const float* bias, const void* residual, long ldr, void* C2, int epi,
-                          int out_mode, int splitk, float alpha, int dtype, hipStream_t stream) {
+                          int out_mode, int splitk, float alpha, double* col_sum, double* col_sumsq, int dtype,
+                          hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return ISTVT_ERR_SHAPE;
     if (out_mode < 0 || out_mode > 3 || epi < 0 || epi > 2) return ISTVT_ERR_SHAPE;
     if (splitk < 1) splitk = 1;
@@ -295,6 +298,8 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epi = epi;
     a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
+    a.st_sum = col_sum; a.st_sumsq = col_sumsq;
+    if ((col_sum == nullptr) != (col_sumsq == nullptr)) return ISTVT_ERR_SHAPE;
     a.gm = 4;             // sweep at the model's shapes: 4 row-panels per tile group is best or neutral everywhere
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + bk - 1) / bk) * bk;
@@ -360,7 +365,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             static const int tm_env = getenv("ISTVT_GEMM_TM") ? atoi(getenv("ISTVT_GEMM_TM")) : 0;
             const int tiles224 = ((M + 223) / 224) * ((N + T256 - 1) / T256);
             const long cost256 = (long)((tiles + cus - 1) / cus) * 256, cost224 = (long)((tiles224 + cus - 1) / cus) * 224;
-            if (tm_env == 224 || (tm_env == -1 && cost224 < cost256)) {
+            if (!col_sum && (tm_env == 224 || (tm_env == -1 && cost224 < cost256))) {
                 const dim3 grid(balanced(tiles224));
                 if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false, 0, 224>), grid, block, 0, stream, a);
                 else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 224>), grid, block, 0, stream, a);
@@ -369,18 +374,24 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 return istvt_check_launch();
             }
             const dim3 grid(balanced(tiles));
+            if (col_sum) {              // fused column statistics: the plain epilogue only (the stem's 1x1 convolutions)
+                if (epi != EPI_NONE || residual) return ISTVT_ERR_SHAPE;
+                hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 256, true>), grid, block, 0, stream, a);
+                return istvt_check_launch();
+            }
             if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), grid, block, 0, stream, a);
             else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), grid, block, 0, stream, a);
             else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((gemm256q_kernel<0, false>), grid, block, 0, stream, a);
             return istvt_check_launch();
         }
-        if (t_ok) {
+        if (t_ok && !col_sum) {
             // weight gradient: unit / ping-pong structure with transposing fragment reads (gemm256t.h)
             hipLaunchKernelGGL(gemm256t_kernel, dim3(tiles, 1, splitk), block, 0, stream, a);
             return istvt_check_launch();
         }
     }
+    if (col_sum) return ISTVT_ERR_SHAPE;        // only the persistent NT kernel accumulates statistics: the host checks first
     DISPATCH_DTYPE(dtype, return launch_gemm<T>(a, a_kc, b_kc, splitk, stream));
     return ISTVT_OK;
 }

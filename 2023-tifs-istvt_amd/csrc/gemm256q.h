@@ -73,9 +73,15 @@ __device__ __forceinline__ void slot_barrier() {
 // out of range: no traffic, zeros in LDS, same instruction and vmcnt counts), phase B then runs 3 instead of 4 row tiles
 // (24 MFMA).  At M = 56 736 this turns 222 row tiles into 254: an N = 728 GEMM is 762 tiles = 2.98 rounds of 256 CUs of
 // tiles that are 12.5 % shorter, instead of 666 = 2.6 rounds that cost 3.  The host picks per launch (gemm.hip).
-template <int EPI, bool SIDE, int DBG = 0, int TM = 256>
+// STATS: also accumulates, per output column, the sum and the sum of squares of the values it STORES (rounded to bf16) into
+// the replicated double accumulators p.st_sum / p.st_sumsq: train-mode BatchNorm statistics of a 1x1 convolution's output
+// without the separate pass that re-reads it (xception.py:44,57 -> :58,69,75).  Per lane 16 float partial sums (its 8
+// columns), kept across the tiles of a workgroup while the column tile stays the same (N <= 256: the whole launch), then
+// reduced over the 8 lanes that share the columns and added with 16 fp64 atomics per lane group.
+template <int EPI, bool SIDE, int DBG = 0, int TM = 256, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     static_assert(TM == 256 || TM == 224, "row tile");
+    static_assert(!STATS || (EPI == 0 && !SIDE && TM == 256), "statistics ride in the plain epilogue only");
     constexpr int NB = (TM - 128) / 32;         // 16-row tiles of the AH unit per wavefront: 4 or 3
     constexpr int HI_HALF = (TM - 128) / 2;     // AH rows per wm half: 64 or 48
     __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
@@ -185,11 +191,41 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const unsigned la_b[2] = {la0 + (wn & 1) * 64 * 128, (la0 ^ 64u) + (wn & 1) * 64 * 128};
     const int b_unit = 1 + (wn >> 1);
 
+    float st1[8], st2[8];
+    int st_bn0 = -1;                            // column tile the partial sums belong to
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+    auto stats_flush = [&]() {
+        if (st_bn0 < 0) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                st1[j] += __shfl_xor(st1[j], o, 64);
+                st2[j] += __shfl_xor(st2[j], o, 64);
+            }
+        }
+        const int col = st_bn0 + wn * 64 + (lane & 7) * 8;
+        if ((lane >> 3) == 0 && col < p.N) {
+            const long rep = (long)(blockIdx.x % ISTVT_STAT_REPLICAS) * 2 * p.N;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(p.st_sum + rep + col + j, (double)st1[j]);
+                atomicAdd(p.st_sumsq + rep + col + j, (double)st2[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+    };
+
     int KT = 0;                                // K tiles consumed so far (stream-wide): slot parity
     int U0 = 0;                                // first unit of the current K tile
     for (int ti = 0; ti < my_tiles; ++ti) {
         int bm0, bn0;
         tile_origin(ti, bm0, bn0);
+        if constexpr (STATS) {
+            if (bn0 != st_bn0) { stats_flush(); st_bn0 = bn0; }
+        }
         // (the output / side descriptors are built where they are used: live across the K loop they cost 12 SGPRs)
         auto side_rs = [&]() {
             return __builtin_amdgcn_make_buffer_rsrc(
@@ -385,6 +421,16 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+                if constexpr (STATS) {
+                    if (voff != OOB) {                  // a row and a column chunk inside the matrix
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float t = (float)o[j];
+                            st1[j] += t;
+                            st2[j] = fmaf(t, t, st2[j]);
+                        }
+                    }
+                }
                 held[it] = __builtin_bit_cast(u32x4, o);
                 __builtin_amdgcn_raw_buffer_store_b128(held[it], c_rs, voff, soff, 0);
                 if (EPI == EPI_GELU_FWD) {
@@ -417,4 +463,5 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             }
         }
     }
+    if constexpr (STATS) stats_flush();
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ void bn_affine8(float (&v)[8], const float* bnp, int 
 // workgroup b adds into replica b % R, and istvt_stats_reduce folds replicas 1..R-1 into replica 0,
 // which is what the consumers (finalize, backward-apply) read.  The C ABI passes pointers to
 // replica 0's two rows.
-constexpr int STAT_REPLICAS = 32;
+constexpr int STAT_REPLICAS = ISTVT_STAT_REPLICAS;
 
 __global__ void stats_reduce_kernel(double* acc, int n2c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

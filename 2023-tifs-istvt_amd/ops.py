@@ -209,7 +209,10 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
 
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
-             C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0):
+             C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0,
+             stats: Optional[Tensor] = None):
+    """stats: double [R][2][N] accumulator (stem.new_stats): the kernel adds the column sums / sums of squares of the
+    stored outputs (fused train-mode BatchNorm statistics); only legal where stats_fusable() says so."""
     _req(A); _req(B); _req(C)
     if A.dtype != B.dtype:
         raise TypeError('gemm operands must share a dtype (%s vs %s)' % (A.dtype, B.dtype))
@@ -221,7 +224,8 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
         ev0.record()
     rc = _lib.lib().istvt_gemm(A.data_ptr(), lda, int(a_kc), B.data_ptr(), ldb, int(b_kc), C.data_ptr(), ldc, M, N, K,
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
-                               dtype_code(A), _stream())
+                               stats[0, 0].data_ptr() if stats is not None else None,
+                               stats[0, 1].data_ptr() if stats is not None else None, dtype_code(A), _stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K),
@@ -230,10 +234,22 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     _lib.check(rc, 'istvt_gemm')
 
 
+def stats_fusable(x: Tensor, w: Tensor) -> bool:
+    """whether linear_fwd(x, w, stats=...) may be used: the problem runs on the persistent bf16 NT kernel (the only one
+    whose epilogue accumulates column statistics)"""
+    M, K = x.shape
+    N = w.shape[0]
+    x2, lda = rows(x)
+    w2, ldb = rows(w)
+    # (with ISTVT_GEMM_TM=224 forced the C side still runs a statistics launch on the 256-row kernel)
+    return (x.dtype == torch.bfloat16
+            and gemm_kernel_name(x2, lda, True, w2, ldb, True, None, N, M, N, K).startswith('gemm256q_kernel<0, false'))
+
+
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               gelu: bool = False, pad: bool = False):
+               gelu: bool = False, pad: bool = False, stats: Optional[Tensor] = None):
     """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype); both may
-    be row-strided views.  pad=True: the outputs are [M, N] views with line-aligned rows."""
+    be row-strided views.  pad=True: the outputs are [M, N] views with line-aligned rows.  stats: see gemm_raw."""
     M, K = x.shape
     N = w.shape[0]
     if w.shape[1] != K:
@@ -249,7 +265,7 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Op
     ldr = 0
     if residual is not None:
         residual, ldr = rows(residual)
-    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr)
+    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr, stats=stats)
     return y
 
 

@@ -67,13 +67,16 @@ def reduce_stats(acc: Tensor, C: int):
 
 
 def bn_forward_stats(u: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor,
-                     training: bool) -> BNState:
+                     training: bool, acc: Optional[Tensor] = None) -> BNState:
+    """acc: statistics already accumulated (not yet reduced) by the producer of u -- the 1x1-convolution GEMM's epilogue
+    (pointwise_bn) -- instead of a pass over u here."""
     st = BNState(C, u.device)
     L = _lib.lib()
     if training:
-        acc = new_stats(C, u.device)
-        _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0, 0].data_ptr(), acc[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
-                   'istvt_bn_stats')
+        if acc is None:
+            acc = new_stats(C, u.device)
+            _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0, 0].data_ptr(), acc[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
+                       'istvt_bn_stats')
         reduce_stats(acc, C)
         s0, s1 = acc[0, 0].data_ptr(), acc[0, 1].data_ptr()
     else:
@@ -82,6 +85,20 @@ def bn_forward_stats(u: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rme
                                    BN_MOMENTUM, BN_EPS, st.ptr(), C, int(training), int(training), _stream()),
                'istvt_bn_finalize')
     return st
+
+
+def pointwise_bn(x: Tensor, w: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor,
+                 training: bool):
+    """u = x @ w.T (a 1x1 convolution on NHWC rows) and the BatchNorm that follows it (xception.py:44,57 -> :58,69,75):
+    in train mode the batch statistics come out of the GEMM's epilogue where the kernel supports it (bf16, the
+    persistent NT kernel), otherwise from the separate istvt_bn_stats pass.  -> (u, BNState)"""
+    acc = None
+    if training and ops.stats_fusable(x, w):
+        acc = new_stats(C, x.device)
+        u = ops.linear_fwd(x, w, stats=acc)
+    else:
+        u = ops.linear_fwd(x, w)
+    return u, bn_forward_stats(u, M, C, gamma, beta, rmean, rvar, training, acc=acc)
 
 
 def bn_apply(u: Tensor, st: BNState, M: int, C: int, relu: bool) -> Tensor:
@@ -208,6 +225,10 @@ class StemFn(Function):
             rm, rv = bufs[name]
             return bn_forward_stats(u, M, C, P[name + '.weight'], P[name + '.bias'], rm, rv, training)
 
+        def pw_bn(name, xin, w, M, C):             # 1x1 convolution + its BatchNorm, statistics from the GEMM epilogue
+            rm, rv = bufs[name]
+            return pointwise_bn(xin, w, M, C, P[name + '.weight'], P[name + '.bias'], rm, rv, training)
+
         # conv1 (3->32, 3x3, s2, p0) as im2col + GEMM
         H1 = (S - 3) // 2 + 1
         M1 = Fr * H1 * H1
@@ -256,16 +277,13 @@ class StemFn(Function):
             wpwB = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0 + 3)], dtype)
             wsk = ops.weight_as(P[name + '.skip.weight'], dtype)
             d1 = dwconv(X, wdwA, Fr, H, H, cin_, in_relu=pre_relu)
-            uA = ops.linear_fwd(d1, wpwA)
-            bnA = bn('%s.rep.%d' % (name, i0 + 1), uA, M, cout)
+            uA, bnA = pw_bn('%s.rep.%d' % (name, i0 + 1), d1, wpwA, M, cout)
             d2 = dwconv(uA, wdwB, Fr, H, H, cout, in_bn=bnA, in_relu=True)
-            uB = ops.linear_fwd(d2, wpwB)
-            bnB = bn('%s.rep.%d' % (name, i0 + 4), uB, M, cout)
+            uB, bnB = pw_bn('%s.rep.%d' % (name, i0 + 4), d2, wpwB, M, cout)
             xs = torch.empty((Ms, cin_), dtype=dtype, device=dev)
             _lib.check(L.istvt_subsample2(X.data_ptr(), xs.data_ptr(), Fr, H, H, cin_, ops._DT[dtype], _stream()),
                        'istvt_subsample2')
-            uS = ops.linear_fwd(xs, wsk)
-            bnS = bn(name + '.skipbn', uS, Ms, cout)
+            uS, bnS = pw_bn(name + '.skipbn', xs, wsk, Ms, cout)
             out = torch.empty((Ms, cout), dtype=dtype, device=dev)
             amax = torch.empty((Ms, cout), dtype=torch.uint8, device=dev)
             _lib.check(L.istvt_pool_add_fwd(uB.data_ptr(), bnB.ptr(), uS.data_ptr(), bnS.ptr(), out.data_ptr(),

@@ -23,7 +23,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib, ops
 from .ops import _c, _req, _stream, dtype_code
-from .stem import bn_apply, bn_backward, bn_forward_stats, dwconv, dwconv_wgrad, new_stats
+from .stem import bn_apply, bn_backward, bn_forward_stats, dwconv, dwconv_wgrad, new_stats, pointwise_bn
 
 Tensor = torch.Tensor
 
@@ -128,8 +128,7 @@ class RepChainFn(Function):
             w9 = _tap_major(wdw)
             wp = ops.weight_as(wpw, dtype)
             d = dwconv(X, w9, Fr, H, W, cin, in_bn=in_bn, in_relu=relu)
-            u = ops.linear_fwd(d, wp)
-            bn = bn_forward_stats(u, M, cout, g, b, rm, rv, training)
+            u, bn = pointwise_bn(d, wp, M, cout, g, b, rm, rv, training)
             units.append(dict(X=X, in_bn=in_bn, relu=relu, d=d, u=u, bn=bn, w9=w9, wp=wp, cin=cin, cout=cout))
             X, in_bn = u, bn
         sk = None
@@ -144,8 +143,7 @@ class RepChainFn(Function):
                 _lib.check(L.istvt_subsample2(inp.data_ptr(), xs.data_ptr(), Fr, H, W, spec.cin, dtc, _stream()), 'istvt_subsample2')
             else:
                 Hs, Ws, xs = H, W, inp
-            uS = ops.linear_fwd(xs, ws)
-            bnS = bn_forward_stats(uS, Fr * Hs * Ws, cout, gs, bs, rms, rvs, training)
+            uS, bnS = pointwise_bn(xs, ws, Fr * Hs * Ws, cout, gs, bs, rms, rvs, training)
             sk = dict(xs=xs, uS=uS, bnS=bnS, ws=ws, Hs=Hs, Ws=Ws)
         amax = None
         if spec.tail == 'pool':

@@ -47,10 +47,15 @@ typedef void* istvt_stream_t; /* hipStream_t */
  * epi: 0 none; 1 GELU forward (exact erf, module.py:28): C = pre-activation, C2 = gelu;
  *      2 GELU backward: C = acc * gelu'(C2).
  * out_mode: 0 store T; 1 store float; 2 atomicAdd into float C; 3 split z stores its float partial
- *           at C + z*M*ldc (caller sums them with istvt_splitk_reduce).  splitk > 1 needs 2 or 3. */
+ *           at C + z*M*ldc (caller sums them with istvt_splitk_reduce).  splitk > 1 needs 2 or 3.
+ * col_sum / col_sumsq (both or neither; NULL = off): replica-0 rows of a double[R][2][N] statistics accumulator (R =
+ *           istvt_stats_replicas()); the kernel adds the per-column sum and sum of squares of the values it stores --
+ *           the train-mode BatchNorm statistics of a 1x1 convolution's output (xception.py:44,57 -> :58,69,75) without a
+ *           second pass.  Only the persistent bf16 NT kernel does this (forward of a >= 64-wide, 16-byte aligned
+ *           problem with epi 0, no residual, out_mode 0); any other combination returns -3. */
 int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
                int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
-               float alpha, int dtype, istvt_stream_t stream);
+               float alpha, double* col_sum, double* col_sumsq, int dtype, istvt_stream_t stream);
 
 /* out[i] += sum_z ws[z*n + i]: second pass of a split-K weight gradient written as partial slabs */
 int istvt_splitk_reduce(const float* ws, int splits, long n, float* out, istvt_stream_t stream);

@@ -780,3 +780,38 @@ def all_checks():  # noqa: F811
     out.append(('stem_convdense_many_chunks_bf16', conv_dense_many_chunks))
     return out
 
+
+
+def gemm_stats_check(M, N, K):
+    """1x1-convolution GEMM with the BatchNorm statistics taken in its epilogue (istvt_gemm col_sum / col_sumsq): the
+    accumulated column sums / sums of squares against float64 sums of the STORED bf16 output; the output itself
+    against the plain launch (bit-identical: same kernel body)."""
+    from istvt_amd import stem as S
+    dt = torch.bfloat16
+    x, w = rnd((M, K), dt, 1), rnd((N, K), dt, 2, K ** -0.5)
+    assert ops.stats_fusable(x, w)
+    acc = S.new_stats(N, DEV)
+    acc[0, 0].fill_(1.0)                                    # accumulates on top of what the buffer holds
+    y = ops.linear_fwd(x, w, stats=acc)
+    S.reduce_stats(acc, N)
+    y0 = ops.linear_fwd(x, w)
+    e = 0.0 if torch.equal(y, y0) else 1.0
+    yd = y.double()
+    e = max(e, relerr(acc[0, 0] - 1.0, yd.sum(0)), relerr(acc[0, 1], (yd * yd).sum(0)))
+    # and through the BatchNorm front end: same pack as the separate statistics pass
+    g, b = rnd((N,), torch.float32, 3, 0.2) + 1, rnd((N,), torch.float32, 4, 0.1)
+    rm1, rv1, rm2, rv2 = (torch.zeros(N, device=DEV), torch.ones(N, device=DEV), torch.zeros(N, device=DEV), torch.ones(N, device=DEV))
+    u1, st1 = S.pointwise_bn(x, w, M, N, g, b, rm1, rv1, True)
+    st2 = S.bn_forward_stats(y0, M, N, g, b, rm2, rv2, True)
+    e = max(e, relerr(st1.pack, st2.pack), relerr(rv1, rv2), float((rm1 - rm2).abs().max() / rv2.sqrt().max()))
+    return e, 2e-5
+
+
+_base5_all_checks = all_checks
+
+
+def all_checks():  # noqa: F811
+    out = _base5_all_checks()
+    for M, N, K in ((3000, 128, 64), (300, 256, 128), (70000, 728, 256), (200704, 128, 128)):
+        out.append(('gemm_bn_stats_M%d_N%d_K%d' % (M, N, K), lambda M=M, N=N, K=K: gemm_stats_check(M, N, K)))
+    return out
