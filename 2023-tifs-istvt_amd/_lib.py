@@ -29,6 +29,7 @@ SIGNATURES = {
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],
     'istvt_stats_replicas': [],
     'istvt_stats_reduce': [P, I, P],
+    'istvt_stats_reduce_add': [P, I, P, P],
     'istvt_bn_stats': [P, P, P, L, I, I, P],
     'istvt_bn_finalize': [P, P, ctypes.c_double, P, P, P, P, F, F, P, I, I, I, P],
     'istvt_bn_apply': [P, P, P, L, I, I, I, P],

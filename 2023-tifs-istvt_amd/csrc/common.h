@@ -159,6 +159,15 @@ __device__ __forceinline__ float xgroup_max(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
+// sum over the 8 lanes that share lane & 7 (lane ^ 8 by a DPP rotate inside the 16-lane row, ^ 16 / ^ 32 by half swaps):
+// no LDS round trip (ds_bpermute) on the way
+__device__ __forceinline__ float xsum_lanes_8_16_32(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float xgroup_sum(float v) {
     auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __uint_as_float(a[0]) + __uint_as_float(a[1]);

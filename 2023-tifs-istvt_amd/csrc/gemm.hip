@@ -34,8 +34,9 @@ struct GemmArgs {
     float alpha;
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
     int gm;               // gemm256q: row-panels per tile group (L2 locality of the tile walk)
-    double* st_sum;       // gemm256q<.., STATS>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
+    double* st_sum;       // gemm256q<.., STATS = 1>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
     double* st_sumsq;     //   (double[R][2][N] accumulators of stem.hip; train-mode BatchNorm statistics of a 1x1 conv)
+                          // gemm256q<.., STATS = 2>: st_sum only (a bias gradient; folded by istvt_stats_reduce_add)
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -299,7 +300,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
     a.st_sum = col_sum; a.st_sumsq = col_sumsq;
-    if ((col_sum == nullptr) != (col_sumsq == nullptr)) return ISTVT_ERR_SHAPE;
+    if (col_sumsq && !col_sum) return ISTVT_ERR_SHAPE;
     a.gm = 4;             // sweep at the model's shapes: 4 row-panels per tile group is best or neutral everywhere
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + bk - 1) / bk) * bk;
@@ -374,9 +375,14 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 return istvt_check_launch();
             }
             const dim3 grid(balanced(tiles));
-            if (col_sum) {              // fused column statistics: the plain epilogue only (the stem's 1x1 convolutions)
+            if (col_sum && col_sumsq) { // fused column statistics: the plain epilogue only (the stem's 1x1 convolutions)
                 if (epi != EPI_NONE || residual) return ISTVT_ERR_SHAPE;
-                hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 256, true>), grid, block, 0, stream, a);
+                hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 256, 1>), grid, block, 0, stream, a);
+                return istvt_check_launch();
+            }
+            if (col_sum) {              // fused column sums of the output: the GELU-backward epilogue (the hidden layer's bias gradient)
+                if (epi != EPI_GELU_BWD) return ISTVT_ERR_SHAPE;
+                hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 256, 2>), grid, block, 0, stream, a);
                 return istvt_check_launch();
             }
             if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), grid, block, 0, stream, a);

@@ -78,10 +78,16 @@ __device__ __forceinline__ void slot_barrier() {
 // without the separate pass that re-reads it (xception.py:44,57 -> :58,69,75).  Per lane 16 float partial sums (its 8
 // columns), kept across the tiles of a workgroup while the column tile stays the same (N <= 256: the whole launch), then
 // reduced over the 8 lanes that share the columns and added with 16 fp64 atomics per lane group.
-template <int EPI, bool SIDE, int DBG = 0, int TM = 256, bool STATS = false>
+// STATS = 2: only the sums (same replicated double accumulator, row 0): the bias gradient of the feed-forward's hidden layer,
+// whose dy is this kernel's GELU-backward output (module.py:27) -- instead of a column-sum pass over the 330 MB tensor.
+// (N = 2912 is 12 column tiles and a workgroup changes column with almost every tile, so it flushes per tile: float
+// atomics straight into the 2912 addresses of the gradient made every launch 60 us longer -- same-address contention --,
+// 32 replicas + istvt_stats_reduce_add do not.)
+template <int EPI, bool SIDE, int DBG = 0, int TM = 256, int STATS = 0>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     static_assert(TM == 256 || TM == 224, "row tile");
-    static_assert(!STATS || (EPI == 0 && !SIDE && TM == 256), "statistics ride in the plain epilogue only");
+    static_assert(STATS != 1 || (EPI == 0 && !SIDE && TM == 256), "BatchNorm statistics ride in the plain epilogue only");
+    static_assert(STATS != 2 || (EPI == EPI_GELU_BWD && TM == 256), "column sums ride in the GELU-backward epilogue only");
     constexpr int NB = (TM - 128) / 32;         // 16-row tiles of the AH unit per wavefront: 4 or 3
     constexpr int HI_HALF = (TM - 128) / 2;     // AH rows per wm half: 64 or 48
     __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
@@ -191,31 +197,38 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const unsigned la_b[2] = {la0 + (wn & 1) * 64 * 128, (la0 ^ 64u) + (wn & 1) * 64 * 128};
     const int b_unit = 1 + (wn >> 1);
 
-    float st1[8], st2[8];
+    float st1[8], st2[STATS == 1 ? 8 : 1];
     int st_bn0 = -1;                            // column tile the partial sums belong to
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) st1[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (STATS == 1 ? 8 : 1); ++j) st2[j] = 0.f;
     auto stats_flush = [&]() {
         if (st_bn0 < 0) return;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-                st1[j] += __shfl_xor(st1[j], o, 64);
-                st2[j] += __shfl_xor(st2[j], o, 64);
-            }
+            st1[j] = xsum_lanes_8_16_32(st1[j]);
+            if constexpr (STATS == 1) st2[j] = xsum_lanes_8_16_32(st2[j]);
         }
         const int col = st_bn0 + wn * 64 + (lane & 7) * 8;
         if ((lane >> 3) == 0 && col < p.N) {
-            const long rep = (long)(blockIdx.x % ISTVT_STAT_REPLICAS) * 2 * p.N;
+            if constexpr (STATS == 1) {
+                const long rep = (long)(blockIdx.x % ISTVT_STAT_REPLICAS) * 2 * p.N;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(p.st_sum + rep + col + j, (double)st1[j]);
-                atomicAdd(p.st_sumsq + rep + col + j, (double)st2[j]);
+                for (int j = 0; j < 8; ++j) {
+                    atomicAdd(p.st_sum + rep + col + j, (double)st1[j]);
+                    atomicAdd(p.st_sumsq + rep + col + j, (double)st2[j]);
+                }
+            } else {
+                const long rep = (long)((blockIdx.x + wm) % ISTVT_STAT_REPLICAS) * 2 * p.N;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(p.st_sum + rep + col + j, (double)st1[j]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+        for (int j = 0; j < 8; ++j) st1[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (STATS == 1 ? 8 : 1); ++j) st2[j] = 0.f;
     };
 
     int KT = 0;                                // K tiles consumed so far (stream-wide): slot parity
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     for (int ti = 0; ti < my_tiles; ++ti) {
         int bm0, bn0;
         tile_origin(ti, bm0, bn0);
-        if constexpr (STATS) {
+        if constexpr (STATS != 0) {
             if (bn0 != st_bn0) { stats_flush(); st_bn0 = bn0; }
         }
         // (the output / side descriptors are built where they are used: live across the K loop they cost 12 SGPRs)
@@ -421,13 +434,13 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-                if constexpr (STATS) {
+                if constexpr (STATS != 0) {
                     if (voff != OOB) {                  // a row and a column chunk inside the matrix
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float t = (float)o[j];
                             st1[j] += t;
-                            st2[j] = fmaf(t, t, st2[j]);
+                            if constexpr (STATS == 1) st2[j] = fmaf(t, t, st2[j]);
                         }
                     }
                 }
@@ -463,5 +476,5 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             }
         }
     }
-    if constexpr (STATS) stats_flush();
+    if constexpr (STATS != 0) stats_flush();
 }

@@ -48,7 +48,22 @@ __global__ void stats_reduce_kernel(double* acc, int n2c) {
     acc[i] = s;
 }
 
+// out[c] += sum over the replicas of row 0 (the column sums a GEMM epilogue accumulated: a bias gradient)
+__global__ void stats_reduce_add_kernel(const double* acc, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < STAT_REPLICAS; ++r) s += acc[(long)r * 2 * C + c];
+    out[c] += (float)s;
+}
+
 extern "C" int istvt_stats_replicas() { return STAT_REPLICAS; }
+
+extern "C" int istvt_stats_reduce_add(const double* acc, int C, float* out, hipStream_t stream) {
+    if (C <= 0 || !acc || !out) return ISTVT_ERR_SHAPE;
+    hipLaunchKernelGGL(stats_reduce_add_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, acc, C, out);
+    return istvt_check_launch();
+}
 
 extern "C" int istvt_stats_reduce(double* acc, int C, hipStream_t stream) {
     if (C <= 0) return ISTVT_ERR_SHAPE;

@@ -268,12 +268,13 @@ class FeedForwardFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, u, g, w1, b1, w2, b2 = ctx.saved_tensors
-        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True)       # (dy W2) * gelu'(u)
+        # (dy W2) * gelu'(u); the hidden layer's bias gradient = its column sums, taken in that GEMM's epilogue
+        buf1, db1 = _target(b1)
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True, csum=buf1)
         dw2 = _wgrad(dy, g, w2)
         db2 = None if ctx.defer_bias else _bgrad(dy, b2)
         dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype, pad=True), pad=True) if ctx.needs_input_grad[0] else None
         dw1 = _wgrad(du, x, w1)
-        db1 = _bgrad(du, b1)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
 
 

@@ -210,9 +210,11 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
              C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0,
-             stats: Optional[Tensor] = None):
+             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None):
     """stats: double [R][2][N] accumulator (stem.new_stats): the kernel adds the column sums / sums of squares of the
-    stored outputs (fused train-mode BatchNorm statistics); only legal where stats_fusable() says so."""
+    stored outputs (fused train-mode BatchNorm statistics); only legal where stats_fusable() says so.
+    csum=True (with stats, epi 2 only): only the column sums are accumulated (a bias gradient; the caller folds them
+    with istvt_stats_reduce_add)."""
     _req(A); _req(B); _req(C)
     if A.dtype != B.dtype:
         raise TypeError('gemm operands must share a dtype (%s vs %s)' % (A.dtype, B.dtype))
@@ -225,7 +227,7 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     rc = _lib.lib().istvt_gemm(A.data_ptr(), lda, int(a_kc), B.data_ptr(), ldb, int(b_kc), C.data_ptr(), ldc, M, N, K,
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
                                stats[0, 0].data_ptr() if stats is not None else None,
-                               stats[0, 1].data_ptr() if stats is not None else None, dtype_code(A), _stream())
+                               stats[0, 1].data_ptr() if (stats is not None and csum is None) else None, dtype_code(A), _stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K),
@@ -299,9 +301,11 @@ def _transposed_operand(w: Tensor) -> Tensor:
 
 
 def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Optional[Tensor] = None,
-                 pad: bool = False) -> Tensor:
+                 pad: bool = False, csum: Optional[Tensor] = None) -> Tensor:
     """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u).
-    wt = w^T [K,N] (optional): use the k-contiguous kernel instead of the transposed-operand one."""
+    wt = w^T [K,N] (optional): use the k-contiguous kernel instead of the transposed-operand one.
+    csum (with gelu_u): float32 [K] += column sums of dx, taken in the GEMM's epilogue where the kernel supports it
+    (else by a colsum pass here): the bias gradient of the Linear whose pre-activation gelu_u is."""
     M, N = dy.shape
     K = w.shape[1]
     dy, lda = rows(dy)
@@ -318,10 +322,24 @@ def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Opt
         wt = _transposed_operand(w)
     if wt is not None:
         wt, ldb = rows(wt)
-        gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi)
+        fuse = (csum is not None and epi == 2 and
+                gemm_kernel_name(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, epi=2).startswith('gemm256q_kernel<2, false'))
+        if fuse:
+            # replicated double accumulator [R][2][K] (row 0 used): per-tile flushes from 256 workgroups into the 2912
+            # addresses of the gradient itself serialise on same-address atomics (+60 us per launch, measured)
+            from . import stem as _stem
+            acc = _stem.new_stats(K, dy.device)
+            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, stats=acc, csum=True)
+            _lib.check(_lib.lib().istvt_stats_reduce_add(acc.data_ptr(), K, csum.data_ptr(), _stream()), 'istvt_stats_reduce_add')
+        else:
+            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi)
+            if csum is not None:
+                colsum(dx, out=csum)
     else:
         w, ldb = rows(w)
         gemm_raw(dy, lda, True, w, ldb, False, dx, ldc, M, K, N, C2=c2, epi=epi)
+        if csum is not None:
+            colsum(dx, out=csum)
     return dx
 
 

@@ -52,7 +52,9 @@ typedef void* istvt_stream_t; /* hipStream_t */
  *           istvt_stats_replicas()); the kernel adds the per-column sum and sum of squares of the values it stores --
  *           the train-mode BatchNorm statistics of a 1x1 convolution's output (xception.py:44,57 -> :58,69,75) without a
  *           second pass.  Only the persistent bf16 NT kernel does this (forward of a >= 64-wide, 16-byte aligned
- *           problem with epi 0, no residual, out_mode 0); any other combination returns -3. */
+ *           problem with epi 0, no residual, out_mode 0); any other combination returns -3.
+ *           col_sum alone (col_sumsq NULL) with epi 2: only the column sums -- the bias gradient of FeedForward's hidden
+ *           layer (module.py:27), whose dy is exactly this GEMM's output; fold with istvt_stats_reduce_add. */
 int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
                int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
                float alpha, double* col_sum, double* col_sumsq, int dtype, istvt_stream_t stream);
@@ -119,6 +121,8 @@ int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int a
  * 1..R-1 into replica 0, which finalize / bwd_apply then read. */
 int istvt_stats_replicas(void);
 int istvt_stats_reduce(double* acc, int C, istvt_stream_t stream);
+/* out[c] += sum over the replicas of row 0: folds column sums accumulated by istvt_gemm(col_sum, NULL) into a float gradient */
+int istvt_stats_reduce_add(const double* acc, int C, float* out, istvt_stream_t stream);
 
 /* train-mode nn.BatchNorm2d (xception.py:58,69,75,119,123): sum/sumsq = rows 0/1 of replica 0 */
 int istvt_bn_stats(const void* x, double* sum, double* sumsq, long M, int C, int dtype, istvt_stream_t stream);

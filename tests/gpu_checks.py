@@ -815,3 +815,29 @@ def all_checks():  # noqa: F811
     for M, N, K in ((3000, 128, 64), (300, 256, 128), (70000, 728, 256), (200704, 128, 128)):
         out.append(('gemm_bn_stats_M%d_N%d_K%d' % (M, N, K), lambda M=M, N=N, K=K: gemm_stats_check(M, N, K)))
     return out
+
+
+def gemm_csum_check(M=5000, N=728, K=2912):
+    """GELU-backward GEMM with the column sums of its output (the hidden layer's bias gradient) taken in the epilogue:
+    output identical to the plain launch, sums against float64 sums of the stored bf16 output, accumulating on top of
+    the buffer's contents."""
+    dt = torch.bfloat16
+    dy, w, u = rnd((M, N), dt, 1), rnd((N, K), dt, 2, N ** -0.5), rnd((M, K), dt, 3)
+    up = ops.empty_rows(M, K, dt, DEV)
+    up.copy_(u)
+    out = torch.full((K,), 3.0, dtype=torch.float32, device=DEV)
+    dx = ops.linear_dgrad(padded(dy), w, gelu_u=up, pad=True, csum=out)
+    dx0 = ops.linear_dgrad(padded(dy), w, gelu_u=up, pad=True)
+    e = 0.0 if torch.equal(dx, dx0) else 1.0
+    ref = dx.double().sum(0)
+    return max(e, float((out.double() - 3.0 - ref).abs().max() / ref.abs().max())), 2e-5
+
+
+_base6_all_checks = all_checks
+
+
+def all_checks():  # noqa: F811
+    out = _base6_all_checks()
+    out.append(('gemm_gelu_bwd_colsum', gemm_csum_check))
+    out.append(('gemm_gelu_bwd_colsum_production', lambda: gemm_csum_check(M_C2, 728, 2912)))
+    return out
