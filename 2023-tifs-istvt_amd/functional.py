@@ -551,6 +551,28 @@ class SeqMeanFn(Function):
         return dx.view(S, n, D)
 
 
+class TakeFrameFn(Function):
+    """x viewed as (B, F, P, D) -> frame 0 of every clip as (B, P, D) with line-aligned rows (the temporal-token frame:
+    the only frame whose last-layer spatial attention reaches the output, vivit.py:144-146).  Backward scatters into a
+    zeroed full-size buffer."""
+
+    @staticmethod
+    def forward(ctx, x, B, F, P):
+        D = x.shape[-1]
+        ctx.geom = (B, F, P, D, x.dtype)
+        out = ops.empty_rows(B * P, D, x.dtype, x.device)
+        out.view(B, P, D).copy_(x.reshape(B, F, P, D)[:, 0])
+        return out.view(B, P, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, F, P, D, dtype = ctx.geom
+        dx = ops.zeros_rows(B * F * P, D, dtype, g.device)
+        dx.view(B, F, P, D)[:, 0] = g
+        return dx.view(B, F * P, D), None, None, None
+
+
 def layer_norm(x, gamma, beta, eps=1e-5, fork=False, sink=None):
     return LayerNormFn.apply(x, gamma, beta, eps, fork, sink)
 

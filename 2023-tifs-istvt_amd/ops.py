@@ -182,7 +182,7 @@ def _cu_count(device) -> int:
 
 
 def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residual=None, bias=None, out_mode=0,
-                     splitk=1, alpha=1.0) -> str:
+                     splitk=1, alpha=1.0, stats=0) -> str:
     """which kernel istvt_gemm launches for these operands (mirrors the dispatch rule in csrc/gemm.hip; the names
     are the ones rocprofv3 prints, so bench.py's per-kernel timings can be checked against profiles/)."""
     big = (A.dtype == torch.bfloat16 and bool(a_kc) == bool(b_kc) and M >= G256_MIN and N >= G256_MIN and N % 8 == 0
@@ -198,7 +198,9 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
             t224 = -(-M // 224) * -(-N // 256)
             tm_env = int(os.environ.get('ISTVT_GEMM_TM', '0'))
             use224 = tm_env == 224 or (tm_env == -1 and -(-t224 // cus) * 224 < -(-t256 // cus) * 256)
-            return 'gemm256q_kernel<%d, %s, 0, %d>' % (epi, side, 224 if use224 else 256)
+            if stats:                   # 1: BatchNorm statistics, 2: column sums in the epilogue (always the 256-row tile)
+                use224 = False
+            return 'gemm256q_kernel<%d, %s, 0, %d, %d>' % (epi, side, 224 if use224 else 256, stats)
         t_ok = (not a_kc and out_mode == 3 and bias is None and residual is None and epi == 0 and K * lda * 2 < 0x7fffffff
                 and K * ldb * 2 < 0x7fffffff)
         if t_ok:
@@ -232,7 +234,7 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K),
                      gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi, residual, bias, out_mode,
-                                      splitk, alpha)))
+                                      splitk, alpha, 0 if stats is None else (2 if csum else 1))))
     _lib.check(rc, 'istvt_gemm')
 
 

@@ -57,6 +57,10 @@ def parse():
                     help='N > 1: one blocking all-reduce after backward instead of starting the transformer slice early')
     ap.add_argument('--torch-optimizer', action='store_true',
                     help='torch.optim.SGD + a separate zero-grad pass instead of the fused HIP optimizer step')
+    ap.add_argument('--dead-row-elimination', action='store_true',
+                    help='opt-in: skip the rows of the last layer that cannot reach the logits (identical results; '
+                         'STTransformer.dead_row_elimination).  Without the flag the default run still reports this '
+                         'variant\'s step time as an extra field')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
     return ap.parse_args()
@@ -158,6 +162,8 @@ def main():
 
     if a.eval:
         model.eval()
+    if a.dead_row_elimination:
+        model.set_dead_row_elimination(True)
 
     def step(reduce=True):
         if a.eval:
@@ -203,6 +209,26 @@ def main():
         per_rank = [round(float(t.item()) / a.steps * 1e3, 3) for t in allt]
         elapsed = max(float(t.item()) for t in allt)
     loss_val = float(loss.item())
+
+    # ---- extra field: the same K steps with the opt-in dead-row elimination (identical logits / gradients, fewer FLOPs)
+    dre = None
+    if not a.eval and not a.dead_row_elimination and a.depth > 1:
+        model.set_dead_row_elimination(True)
+        step(); step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        dre = {'ms_per_step': round(e2 / a.steps * 1e3, 3), 'clips_per_s': round(world * a.batch * a.steps / e2, 3),
+               'note': 'opt-in STTransformer.dead_row_elimination: last-layer rows that cannot reach the logits skipped, '
+                       'results identical; NOT the headline value'}
+        model.set_dead_row_elimination(False)
 
     # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
     roof = None
@@ -297,6 +323,9 @@ def main():
         # bound.  (Replaying the step as one captured HIP graph was tried: hipGraphLaunch of the 1500-node graph costs
         # the host 35 ms per replay on this ROCm, no better than the eager loop.)
         out['host_enqueue_ms_per_step'] = round(t_enq * 1e3, 3)
+        out['config']['dead_row_elimination'] = bool(a.dead_row_elimination)
+        if dre:
+            out['with_dead_row_elimination'] = dre
         if world > 1:
             out['distributed'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                   'per_rank_ms_per_step': per_rank,

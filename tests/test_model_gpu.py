@@ -638,3 +638,43 @@ def test_data_parallel_equals_single_process():
     print(r.stdout[-2500:])
     assert r.returncode == 0, r.stdout[-3000:]
     assert 'data-parallel equivalence' in r.stdout
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dead_row_elimination_is_exact(dtype):
+    """STTransformer.dead_row_elimination (opt-in): the last layer's spatial block on frame 0 only and its feed-forward on
+    the class rows only -- the rows DSTTr never reads (vivit.py:144-146) are skipped.  Logits and every gradient equal the
+    full computation (float32: to summation order; bfloat16: the same kernels on fewer rows, equal to bf16 rounding)."""
+    R, p, x, labels, grid = _oracle_case(2, 4, 96, 2)
+    res = []
+    for on in (False, True):
+        model = _hip_model(p, 4, grid, 2, dtype=dtype).set_dead_row_elimination(on)
+        out = model(x.cuda())
+        torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+        res.append((out.detach().clone(), {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None}))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert relerr(res[1][0], res[0][0]) < tol
+    assert sorted(res[0][1]) == sorted(res[1][1])
+    worst = max((relerr(res[1][1][k], v), k) for k, v in res[0][1].items())
+    assert worst[0] < (1e-4 if dtype == torch.float32 else 5e-2), worst
+
+
+def test_dead_row_elimination_matches_reference_golden(golden_dir):
+    """G4 (reference DSTTr capture, grid 19, T = 8) with the opt-in on: same logits and gradient norms."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network.vivit import vivit as V
+    g = np.load(os.path.join(golden_dir, 'G4_dsttr.npz'))
+    mod = V.DSTTr(19, 1, 1, 8, dim=64, depth=2, heads=2, dim_head=32, in_channels=64, scale_dim=2)
+    sd = mod.state_dict()
+    mod.load_state_dict({k: torch.from_numpy(recipe.param_value('g4.' + k, tuple(v.shape))) for k, v in sd.items()})
+    mod = mod.cuda().train()
+    mod.transformer.dead_row_elimination = True
+    x = torch.from_numpy(recipe.input_value('g4.x.T8', (2, 8, 64, 19, 19))).cuda().requires_grad_(True)
+    y = mod(x)
+    coef = torch.from_numpy(recipe.input_value('g4.coef', tuple(y.shape))).cuda()
+    (y * coef).sum().backward()
+    assert relerr(y, g['T8.logits']) < 1e-4
+    assert relerr(x.grad.flatten(2).norm(dim=2), g['T8.dx_frame_norms']) < 1e-3
+    for k, q in mod.named_parameters():
+        assert relerr(q.grad.norm(), g['T8.gnorm.' + k]) < 1e-3, k
