@@ -389,6 +389,9 @@ def pool_check(dtype, Fr=2, H=21, W=21, C=24):
     return max(relerr(out, _nhwc(ref)), relerr(dz, _nhwc(z.grad))), TOL[dtype]
 
 
+Y_TOL_BF16 = 2e-2
+
+
 def stem_vs_oracle(dtype, side=96, n=2, need_dx=True, init='recipe', tol=None):
     """whole entry flow, forward + every parameter gradient, against the CPU oracle (fp32).
 
@@ -436,7 +439,15 @@ def stem_vs_oracle(dtype, side=96, n=2, need_dx=True, init='recipe', tol=None):
     # (1 - cosine) while the forward, where near-kink elements contribute ~0, stays tight.
     gerr = relerr if dtype == torch.float32 else \
         (lambda a, b: 1.0 - float(torch.nn.functional.cosine_similarity(a.double().flatten(), b.double().flatten(), dim=0)))
-    errs = {'y': relerr(y.cpu(), yr.detach()) * (1.0 if dtype == torch.float32 else 0.5)}
+    yerr = relerr(y.cpu(), yr.detach())
+    stem_vs_oracle.last_y = yerr
+    if dtype == torch.float32:
+        errs = {'y': yerr}
+    else:
+        # the bf16 forward has its own, tight bound (measured 1.2e-2 / 1.3e-2 at 139^2 / 224^2 over the
+        # six conv+BN layers); only the gradients below are judged as directions
+        assert yerr <= Y_TOL_BF16, 'bf16 stem forward: relative error %.4f > %.3f' % (yerr, Y_TOL_BF16)
+        errs = {}
     if need_dx:
         errs['dx'] = gerr(x.grad.cpu(), xc.grad)
     named = dict(net.named_parameters())
@@ -467,7 +478,8 @@ def all_checks():  # noqa: F811
             # |z| ~ 1e-5 (fp32 summation-order noise) moves early-layer gradients by a few percent.
             out.append(('stem_oracle_96_%s' % tag, lambda dt=dt: stem_vs_oracle(dt, 96, tol=1e-1)))
             out.append(('stem_oracle_139_%s' % tag, lambda dt=dt: stem_vs_oracle(dt, 139)))
-        rt = 5e-3 if dt == torch.float32 else 0.15     # f32: a handful of kink flips; bf16: 1 - cosine / y relerr * 0.5
+        rt = 5e-3 if dt == torch.float32 else 0.13     # f32: a handful of kink flips; bf16: 1 - cosine of the gradients
+        # (measured 0.067 at 139^2, 0.096 at 224^2); the bf16 forward is bounded separately by Y_TOL_BF16
         out.append(('stem_oracle_random_139_%s' % tag, lambda dt=dt, rt=rt: stem_vs_oracle(dt, 139, init='random', tol=rt)))
         out.append(('stem_oracle_random_224_%s' % tag,
                     lambda dt=dt, rt=rt: stem_vs_oracle(dt, 224, init='random', need_dx=False, tol=rt)))
