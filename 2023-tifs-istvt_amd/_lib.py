@@ -8,7 +8,8 @@ import os
 from ctypes import c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libistvt_hip.so')
+# ISTVT_LIB: another build of the same library (same-box A/B of a kernel change); it must export the same entry points
+LIB_PATH = os.environ.get('ISTVT_LIB') or os.path.join(_HERE, 'libistvt_hip.so')
 
 P, I, L, F = c_void_p, c_int, c_long, c_float
 
@@ -53,6 +54,8 @@ SIGNATURES = {
     'istvt_pool_bwd': [P, P, P, I, I, I, I, I, P],
     'istvt_subsample2': [P, P, I, I, I, I, I, P],
     'istvt_splitk_reduce': [P, I, L, P, P],
+    'istvt_wgrad_group': [I, P, P, P, P, P, P, P, I, I, P, L, P],
+    'istvt_wgrad_group_splits': [I, P, P, I],
     'istvt_colsum': [P, P, L, I, L, I, P],
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],

@@ -39,7 +39,7 @@ def _compile(src):
 
 # Kernels whose loads are inline-asm (the compiler does not know their results arrive late): a register spill
 # there would store a not-yet-landed value, silently.  The build fails instead.
-NO_SPILL_KERNELS = ('gemm256q_kernel', 'gemm256t_kernel')
+NO_SPILL_KERNELS = ('gemm256q_kernel', 'gemm256t_kernel', 'gemm256t_group_kernel')
 
 
 def _check_no_spills(src, remarks):

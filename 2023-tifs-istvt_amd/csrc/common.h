@@ -30,6 +30,17 @@ enum { DT_F32 = 0, DT_BF16 = 1 };
 // per-channel statistics accumulators are double[ISTVT_STAT_REPLICAS][2][C] (see stem.hip); producers add into replica
 // (workgroup % ISTVT_STAT_REPLICAS)
 constexpr int ISTVT_STAT_REPLICAS = 32;
+// The hardware deals the workgroup ids of a 1-D grid round-robin to the 8 XCDs (id & 7), each with its own L2:
+// neighbours in blockIdx.x never share an L2.  xcd_chunk() renumbers the grid (a bijection on 0..nwg-1) so that the
+// workgroups of one XCD hold a CONTIGUOUS eighth of the work list -- tiles that share halo rows / operand panels then
+// meet in one L2 instead of each fetching its own copy from HBM.
+__device__ __forceinline__ int xcd_chunk(const int id, const int nwg) {
+    const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+}
+
+// weight gradients launched together by istvt_wgrad_group (gemm256t.h)
+constexpr int ISTVT_WGRAD_GROUP_MAX = 8;
 
 static inline int istvt_check_launch() {
     hipError_t e = hipGetLastError();

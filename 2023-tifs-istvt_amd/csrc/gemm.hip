@@ -393,7 +393,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         }
         if (t_ok && !col_sum) {
             // weight gradient: unit / ping-pong structure with transposing fragment reads (gemm256t.h)
-            hipLaunchKernelGGL(gemm256t_kernel, dim3(tiles, 1, splitk), block, 0, stream, a);
+            hipLaunchKernelGGL(gemm256t_kernel, dim3(tiles * splitk), block, 0, stream, a);
             return istvt_check_launch();
         }
     }
@@ -425,4 +425,104 @@ extern "C" int istvt_splitk_reduce(const float* ws, int splits, long n, float* o
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ws, splits, n, out);
     return istvt_check_launch();
+}
+
+
+// ---- grouped weight gradients ---------------------------------------------------------------------------------------
+struct ReduceGroupArgs {
+    const float* ws[ISTVT_WGRAD_GROUP_MAX];
+    float* out[ISTVT_WGRAD_GROUP_MAX];
+    long n[ISTVT_WGRAD_GROUP_MAX];
+    int start[ISTVT_WGRAD_GROUP_MAX + 1];
+    int count, splits;
+};
+
+// out_i[e] += sum_z ws_i[z][e] for every problem of a group: problem i owns blocks start[i] .. start[i+1]-1
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroupArgs g) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < ISTVT_WGRAD_GROUP_MAX; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.start[i]) pi = i;
+    const float* __restrict__ ws = g.ws[pi];
+    float* __restrict__ out = g.out[pi];
+    const long n = g.n[pi];
+    const int blocks = g.start[pi + 1] - g.start[pi], b = blockIdx.x - g.start[pi];
+    const long stride = (long)blocks * 256 * 4;
+    for (long i = ((long)b * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        float4 acc = *reinterpret_cast<const float4*>(out + i);
+#pragma unroll 8
+        for (int z = 0; z < g.splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (long)z * n + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = acc;
+    }
+}
+
+// out_i[N_i][K_i] += dy_i^T x_i for i < count: dy_i [M][N_i], x_i [M][K_i] bf16 with row strides lddy_i / ldx_i, out_i
+// contiguous float.  All problems share the reduction length M and the split count; ws holds splits * sum(N_i K_i)
+// floats (problem i's slabs start at splits * sum_{j<i} N_j K_j).  splits <= 0: as many as fill 256 workgroups.
+// Returns ISTVT_ERR_SHAPE for problems the 256x256 weight-gradient kernel does not take (the caller then launches
+// them one by one through istvt_gemm).
+extern "C" int istvt_wgrad_group(int count, const void* const* dy, const long* lddy, const void* const* x, const long* ldx,
+                                 float* const* out, const int* N, const int* K, int M, int splits, float* ws,
+                                 long ws_elems, hipStream_t stream) {
+    if (count < 1 || count > ISTVT_WGRAD_GROUP_MAX || M <= 0 || !ws) return ISTVT_ERR_SHAPE;
+    GemmGroupArgs g;
+    ReduceGroupArgs rg;
+    int tiles_total = 0;
+    long elems = 0;
+    for (int i = 0; i < count; ++i) {
+        if (N[i] < ISTVT_G256_MIN || K[i] < ISTVT_G256_MIN || N[i] % 8 || K[i] % 8) return ISTVT_ERR_SHAPE;
+        if (((uintptr_t)dy[i] % 16) || ((uintptr_t)x[i] % 16) || (lddy[i] * 2) % 16 || (ldx[i] * 2) % 16 ||
+            ((uintptr_t)out[i] % 16)) return ISTVT_ERR_SHAPE;
+        if ((long)M * lddy[i] * 2 >= 0x7fffffffL || (long)M * ldx[i] * 2 >= 0x7fffffffL) return ISTVT_ERR_SHAPE;
+        tiles_total += ((N[i] + T256 - 1) / T256) * ((K[i] + T256 - 1) / T256);
+        elems += (long)N[i] * K[i];
+    }
+    if (splits <= 0) splits = 256 / tiles_total;
+    if (splits < 1) splits = 1;
+    if (splits > (M + 63) / 64) splits = (M + 63) / 64;
+    int kper = (M + splits - 1) / splits;
+    kper = ((kper + 63) / 64) * 64;
+    splits = (M + kper - 1) / kper;
+    if (ws_elems < (long)splits * elems) return ISTVT_ERR_SHAPE;
+    int start = 0, rstart = 0;
+    long off = 0;
+    for (int i = 0; i < count; ++i) {
+        GemmArgs& a = g.p[i];
+        a = GemmArgs{};
+        // the kernel's (M, N, K) are (output rows, output columns, reduction length)
+        a.A = dy[i]; a.B = x[i]; a.C = ws + off; a.lda = lddy[i]; a.ldb = ldx[i]; a.ldc = K[i];
+        a.M = N[i]; a.N = K[i]; a.K = M; a.kper = kper; a.alpha = 1.0f; a.out_f32 = 1; a.a_vec = a.b_vec = 1;
+        a.slab = (long)N[i] * K[i]; a.gm = 4;
+        g.start[i] = start;
+        const int tiles = ((N[i] + T256 - 1) / T256) * ((K[i] + T256 - 1) / T256);
+        start += tiles * splits;
+        rg.ws[i] = ws + off; rg.out[i] = out[i]; rg.n[i] = (long)N[i] * K[i];
+        rg.start[i] = rstart;
+        long blocks = (rg.n[i] / 4 + 255) / 256;
+        if (blocks > 512) blocks = 512;
+        rstart += (int)blocks;
+        off += (long)splits * N[i] * K[i];
+    }
+    for (int i = count; i <= ISTVT_WGRAD_GROUP_MAX; ++i) { g.start[i] = start; rg.start[i] = rstart; }
+    g.n = count; rg.count = count; rg.splits = splits;
+    hipLaunchKernelGGL(gemm256t_group_kernel, dim3(start), dim3(512), 0, stream, g);
+    int rc = istvt_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(rstart), dim3(256), 0, stream, rg);
+    return istvt_check_launch();
+}
+
+// the split count istvt_wgrad_group(splits <= 0) would use: sizes the workspace
+extern "C" int istvt_wgrad_group_splits(int count, const int* N, const int* K, int M) {
+    if (count < 1 || count > ISTVT_WGRAD_GROUP_MAX || M <= 0) return ISTVT_ERR_SHAPE;
+    int tiles_total = 0;
+    for (int i = 0; i < count; ++i) tiles_total += ((N[i] + T256 - 1) / T256) * ((K[i] + T256 - 1) / T256);
+    int splits = 256 / tiles_total;
+    if (splits < 1) splits = 1;
+    if (splits > (M + 63) / 64) splits = (M + 63) / 64;
+    int kper = (((M + splits - 1) / splits + 63) / 64) * 64;
+    return (M + kper - 1) / kper;
 }

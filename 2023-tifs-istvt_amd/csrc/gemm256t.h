@@ -35,7 +35,16 @@ __device__ __forceinline__ bf16x8 t_frag(const char* img, int k0, int col16, int
     return __builtin_bit_cast(bf16x8, s);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
+// Workgroup placement.  The hardware deals workgroup ids round-robin to the 8 XCDs (id & 7), each with its own L2.
+// xcd_chunk() (common.h) renumbers the grid so that the workgroups of one XCD hold a CONTIGUOUS run of the (split z, tile) list:
+// with ~32 workgroups resident per XCD that run is one split's tiles in row-major order -- for a 3 x 12-tile
+// gradient 3 row panels + 12 column panels feed 32 tiles (L2 hit rate ~75 % of the panel reads).  The earlier map
+// ((tile & 7) taken as the XCD with the split on grid.z, which it is not when the tile count is not a multiple
+// of 8) left every XCD with tiles of all splits: rocprof FETCH_SIZE 720 MB per launch against 206 MB of operands.
+
+// One (tile, reduction split) of problem p: wg = the tile's index (row-major over the 256x256 output tiles), z = the
+// reduction split.
+__device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, const int z) {
     __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,15 +52,10 @@ __global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int lda = (int)p.lda, ldb = (int)p.ldb, ldc = (int)p.ldc;
 
-    const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + T256 - 1) / T256;
-    const int nwg = tiles_n * tiles_m;
-    int id = blockIdx.x;
-    {   // XCD-aware order (bijective): workgroups that share an XCD walk consecutive tiles
-        const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
-        id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
-    }
+    const int tiles_n = (p.N + T256 - 1) / T256;
+    const int id = wg;
     const int bm0 = (id / tiles_n) * T256, bn0 = (id % tiles_n) * T256;
-    const int k_begin = blockIdx.z * p.kper;
+    const int k_begin = z * p.kper;
     const int k_end = min(p.K, k_begin + p.kper);
     const int nkt = (k_end - k_begin + 63) >> 6;
     const int total_u = nkt * 4;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
     const bool n_ok = bn0 + col_w < p.N;                   // N % 8 == 0: a chunk of 8 columns is all in or all out
     const int rows_left = p.M - bm0 - row_w;
     const unsigned c_off = n_ok ? (unsigned)((row_w * ldc + col_w) * 4) : OOB;
-    const long c_org = ((long)blockIdx.z * p.slab + (long)bm0 * ldc + bn0) * 4;
+    const long c_org = ((long)z * p.slab + (long)bm0 * ldc + bn0) * 4;
     const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr((char*)p.C + c_org), 0, WINDOW, RSRC_FLAGS);
     const int re = lane & 15, ge = lane >> 4, l7 = lane & 7;
 #pragma unroll
@@ -198,4 +202,35 @@ __global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     }
+}
+
+// grid.x = tiles * splits
+__global__ __launch_bounds__(512, 2) void gemm256t_kernel(GemmArgs p) {
+    const int tiles = ((p.N + T256 - 1) / T256) * ((p.M + T256 - 1) / T256);
+    const int L = xcd_chunk(blockIdx.x, gridDim.x);
+    const int z = L / tiles;
+    gemm256t_body(p, L - z * tiles, z);
+}
+
+// Several weight gradients with the same reduction length in ONE launch (all eight of a transformer layer: 120 tiles,
+// so two reduction splits fill the chip instead of 7..42 per GEMM launched alone -- the fp32 slab traffic falls from
+// 512 MB to 60 MB per layer and the launch has one ramp and one tail).  Problem i owns entries start[i] ..
+// start[i+1]-1 (= tiles_i * splits of them, split-major) of the renumbered grid.
+struct GemmGroupArgs {
+    GemmArgs p[ISTVT_WGRAD_GROUP_MAX];
+    int start[ISTVT_WGRAD_GROUP_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm256t_group_kernel(GemmGroupArgs g) {
+    const int L = xcd_chunk(blockIdx.x, gridDim.x);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < ISTVT_WGRAD_GROUP_MAX; ++i)
+        if (i < g.n && L >= g.start[i]) pi = i;
+    const GemmArgs& p = g.p[pi];
+    const int l = L - g.start[pi];
+    const int tiles = ((p.N + T256 - 1) / T256) * ((p.M + T256 - 1) / T256);
+    const int z = l / tiles;
+    gemm256t_body(p, l - z * tiles, z);
 }

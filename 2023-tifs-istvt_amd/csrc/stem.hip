@@ -559,8 +559,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     // 1-D grid, channel chunk fastest: the workgroups that share a pixel's 128-byte lines (its other
     // channel chunks) are dispatched back to back and meet in L2 instead of re-fetching from HBM
     const int nch = (p.C + DW_CC - 1) / DW_CC;
-    const long t = blockIdx.x / nch;
-    const int c0 = (int)(blockIdx.x % nch) * DW_CC;
+    const int bid = xcd_chunk(blockIdx.x, gridDim.x);    // an XCD's workgroups: a contiguous run of tiles (shared halos)
+    const long t = bid / nch;
+    const int c0 = (int)(bid % nch) * DW_CC;
     const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
     const long f = t / (tiles_x * tiles_y);
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
@@ -734,14 +735,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
     const long ntiles = (long)Fr * tiles_x * tiles_y;
     const int nch = (C + DW_CC - 1) / DW_CC;                 // 1-D grid, channel chunk fastest (L2 sharing)
-    const int c0 = (int)(blockIdx.x % nch) * DW_CC;
+    const int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int c0 = (int)(bid % nch) * DW_CC;
     const int ch = tid % DW_NCH, c = c0 + ch * 8;
     float acc[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    for (long t = blockIdx.x / nch; t < ntiles; t += gridDim.x / nch) {
+    for (long t = bid / nch; t < ntiles; t += gridDim.x / nch) {
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const long f = t / (tiles_x * tiles_y);
         const int y0 = ty * DW_TH, x0 = tx * DW_TW;
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
                                                            int H, int W, int C, int Ho, int Wo) {
     const int vpr = C / 8;
     const long nitems = Mo * vpr, stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+    for (long i = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < nitems; i += stride) {   // windows of neighbouring rows overlap: keep them in one XCD's L2
         const int ch = (int)(i % vpr);
         const long m = i / vpr;
         const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
                                                        int Wo) {
     const int vpr = C / 8;
     const long nitems = Mi * vpr, stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
+    for (long i = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < nitems; i += stride) {   // windows of neighbouring rows overlap: keep them in one XCD's L2
         const int ch = (int)(i % vpr);
         const long m = i / vpr;
         const int x = (int)(m % W), y = (int)((m / W) % H);

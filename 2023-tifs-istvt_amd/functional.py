@@ -124,16 +124,28 @@ class FrameDiffFn(Function):
 # bandwidth-bound kernels leave idle, with weight-gradient workgroups.  Only used when the gradient lands directly
 # in the parameter's .grad (GradBucket(fuse_accumulate=True)): a returned tensor would be consumed by autograd on
 # the main stream.  ISTVT_WGRAD_STREAM=0 (or set_wgrad_overlap(False)) serialises everything on one stream.
-_overlap = {'on': os.environ.get('ISTVT_WGRAD_STREAM', '1') != '0', 'streams': {}, 'pending': {}, 'keep': {}}
+_overlap = {'on': os.environ.get('ISTVT_WGRAD_STREAM', '1') != '0', 'streams': {}, 'pending': {}, 'keep': {},
+            # Grouping: the weight gradients of up to 8 Linears with the same row count (one transformer layer) are queued
+            # and launched as ONE (tile, split) grid (ops.linear_wgrad_group): 120 tiles need 2 reduction splits to fill
+            # the chip instead of 7..42 per GEMM alone, so the fp32 partial slabs shrink from 512 MB to 60 MB per layer.
+            'group': int(os.environ.get('ISTVT_WGRAD_GROUP', '8')), 'queue': {}}
 
 
 def set_wgrad_overlap(on: bool):
     _overlap['on'] = bool(on)
 
 
+def set_wgrad_group(n: int):
+    """how many weight gradients are launched together (1: each on its own, as they are produced)"""
+    if not 1 <= int(n) <= ops.WGRAD_GROUP_MAX:
+        raise ValueError('weight-gradient group size must be in 1..%d' % ops.WGRAD_GROUP_MAX)
+    _overlap['group'] = int(n)
+
+
 def join_side_stream(dev=None):
     """Make the current backward's main stream wait for the side stream now (instead of at the end of backward): what a
-    caller needs before it hands weight gradients to a collective mid-backward."""
+    caller needs before it hands weight gradients to a collective mid-backward.  Queued weight gradients are launched
+    first."""
     if dev is None:
         dev = torch.cuda.current_device()
     _join_side(dev)
@@ -146,6 +158,28 @@ def join_side_stream(dev=None):
 grad_ready_hooks = []
 
 
+def _flush_group(dev):
+    """launch the queued weight gradients (on the side stream when the overlap is on, else on the current stream)"""
+    q = _overlap['queue'].pop(dev, None)
+    if not q:
+        return
+    if _overlap['on']:
+        side = _side_stream(torch.device('cuda', dev))
+        side.wait_stream(torch.cuda.current_stream(torch.device('cuda', dev)))
+        with torch.cuda.stream(side):
+            ops.linear_wgrad_group(q)
+    else:
+        ops.linear_wgrad_group(q)
+
+
+def _side_stream(device):
+    dev = device.index
+    side = _overlap['streams'].get(dev)
+    if side is None:
+        side = _overlap['streams'][dev] = torch.cuda.Stream(device=device, priority=int(os.environ.get('ISTVT_WGRAD_PRIO', '0')))
+    return side
+
+
 def _join_side(dev, task=None):
     """task: the autograd graph task whose end-of-backward callback this is (None: join whatever is pending).  A
     callback of an EARLIER task whose entry has already been flushed and replaced must not touch the new entry."""
@@ -153,7 +187,10 @@ def _join_side(dev, task=None):
     if ent is None or (task is not None and ent[1] != task):
         return
     del _overlap['pending'][dev]
-    ent[0].wait_stream(_overlap['streams'][dev])
+    _flush_group(dev)
+    side = _overlap['streams'].get(dev)
+    if side is not None:
+        ent[0].wait_stream(side)
     # The operands of the side-stream launches were kept alive until here instead of being handed to the allocator with
     # record_stream(): blocks parked behind side-stream events made the caching allocator grow by a run-dependent
     # 16-56 GB at C2 (reserved 47-87 GB against 31 GB single-stream).  Released after the join they go back to the main
@@ -170,7 +207,8 @@ def flush_stale_joins():
     end-of-backward callback: its join entry and the operands it keeps alive would stay behind, every later backward
     would skip registering a join and the optimizer would read weight gradients the side stream may still be writing.
     Called from the forward (outside any backward every entry is stale) and from _wgrad (an entry of another graph
-    task is stale): joins the side stream into the CURRENT stream and drops the entry."""
+    task is stale): joins the side stream into the CURRENT stream and drops the entry; weight gradients of the
+    aborted pass that were still queued are dropped with it (its gradients are garbage anyway)."""
     if not _overlap['pending']:
         return
     task = _graph_task()
@@ -180,19 +218,18 @@ def flush_stale_joins():
             if side is not None:
                 torch.cuda.current_stream(torch.device('cuda', dev)).wait_stream(side)
             del _overlap['pending'][dev]
+            _overlap['queue'].pop(dev, None)
             _overlap['keep'].pop(dev, None)
 
 
 def _wgrad(dy, x, weight):
     buf, ret = _target(weight)
     out = buf.view(weight.shape[0], -1)
-    if not (_overlap['on'] and ret is None and dy.is_cuda):
+    group = _overlap['group']
+    if not (ret is None and dy.is_cuda and (_overlap['on'] or group > 1)):
         ops.linear_wgrad(dy, x, out=out)
         return ret
     dev = dy.device.index
-    side = _overlap['streams'].get(dev)
-    if side is None:
-        side = _overlap['streams'][dev] = torch.cuda.Stream(device=dy.device, priority=int(os.environ.get('ISTVT_WGRAD_PRIO', '0')))
     main = torch.cuda.current_stream(dy.device)
     task = _graph_task()
     ent = _overlap['pending'].get(dev)
@@ -202,8 +239,22 @@ def _wgrad(dy, x, weight):
     if ent is None:
         _overlap['pending'][dev] = (main, task)
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev, task))
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
+    if group > 1 and out.is_contiguous() and ops.wgrad_groupable(dy, x):
+        q = _overlap['queue'].get(dev)
+        if q and (q[0][0].shape[0] != dy.shape[0] or any(o.data_ptr() == out.data_ptr() for _, _, o in q)):
+            _flush_group(dev)                    # another row count (the row-pruned last layer) or a shared weight
+            q = None
+        if q is None:
+            q = _overlap['queue'][dev] = []
+        q.append((dy, x, out))
+        if len(q) >= group:
+            _flush_group(dev)
+    elif _overlap['on']:
+        side = _side_stream(dy.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.linear_wgrad(dy, x, out=out)
+    else:
         ops.linear_wgrad(dy, x, out=out)
     _overlap['keep'].setdefault(dev, []).append((dy, x))     # alive until the join (see _join_side)
     return None

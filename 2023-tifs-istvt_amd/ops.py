@@ -383,6 +383,61 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+WGRAD_GROUP_MAX = 8
+
+
+def wgrad_groupable(dy: Tensor, x: Tensor) -> bool:
+    """whether linear_wgrad_group takes this weight gradient (the 256x256 bf16 TN kernel's conditions)"""
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dy.dim() != 2 or x.dim() != 2:
+        return False
+    M, N = dy.shape
+    K = x.shape[1]
+    if N < G256_MIN or K < G256_MIN or N % 8 or K % 8 or x.shape[0] != M:
+        return False
+    for t in (dy, x):
+        if t.stride(1) != 1 or (t.stride(0) * 2) % 16 or t.data_ptr() % 16 or M * t.stride(0) * 2 >= 0x7fffffff:
+            return False
+    return True
+
+
+def linear_wgrad_group(items) -> None:
+    """items: [(dy [M, N_i], x [M, K_i], out float [N_i, K_i])] with one M, each accepted by wgrad_groupable():
+    out_i += dy_i.T @ x_i for all of them in one GEMM launch + one reduce launch (istvt_wgrad_group)."""
+    import ctypes as C
+    n = len(items)
+    if not 1 <= n <= WGRAD_GROUP_MAX:
+        raise RuntimeError('linear_wgrad_group: %d problems (1..%d)' % (n, WGRAD_GROUP_MAX))
+    M = items[0][0].shape[0]
+    Ns, Ks = [], []
+    for dy, x, out in items:
+        _req(dy); _req(x); _req(out)
+        if dy.shape[0] != M or not wgrad_groupable(dy, x):
+            raise RuntimeError('linear_wgrad_group: problem not groupable: dy %s x %s' % (tuple(dy.shape), tuple(x.shape)))
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != dy.shape[1] * x.shape[1]:
+            raise RuntimeError('linear_wgrad_group: out must be a contiguous float [N, K] buffer')
+        Ns.append(dy.shape[1]); Ks.append(x.shape[1])
+    PA, LA, IA = C.c_void_p * n, C.c_long * n, C.c_int * n
+    a_n, a_k = IA(*Ns), IA(*Ks)
+    lib = _lib.lib()
+    splits = lib.istvt_wgrad_group_splits(n, a_n, a_k, M)
+    if splits < 1:
+        _lib.check(splits, 'istvt_wgrad_group_splits')
+    elems = sum(a * b for a, b in zip(Ns, Ks))
+    ws = torch.empty((splits * elems,), dtype=torch.float32, device=items[0][0].device)
+    prof = gemm_profile
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.istvt_wgrad_group(n, PA(*[it[0].data_ptr() for it in items]), LA(*[it[0].stride(0) for it in items]),
+                               PA(*[it[1].data_ptr() for it in items]), LA(*[it[1].stride(0) for it in items]),
+                               PA(*[it[2].data_ptr() for it in items]), a_n, a_k, M, splits, ws.data_ptr(),
+                               ws.numel(), _stream())
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * elems, (False, False), (max(Ns), max(Ks), M), 'gemm256t_group_kernel(GemmGroupArgs)'))
+    _lib.check(rc, 'istvt_wgrad_group')
+
+
 def colsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     M, N = x.shape
     x, ld = rows(_req(x))

@@ -62,6 +62,18 @@ int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b
 /* out[i] += sum_z ws[z*n + i]: second pass of a split-K weight gradient written as partial slabs */
 int istvt_splitk_reduce(const float* ws, int splits, long n, float* out, istvt_stream_t stream);
 
+/* Weight gradients of up to 8 nn.Linear layers in one launch pair (the eight of one transformer layer: module.py:27,30,
+ * 74,77,182,183,186 as they come out of the backward pass): out_i[N_i][K_i] += dy_i^T x_i, dy_i bf16 [M][N_i] (row
+ * stride lddy_i), x_i bf16 [M][K_i] (row stride ldx_i), out_i contiguous float.  The problems share the reduction
+ * length M, so one grid of (tile, split) workgroups covers all of them with few reduction splits; ws: scratch of at
+ * least splits * sum(N_i K_i) floats.  splits <= 0: chosen so that the grid fills the chip
+ * (istvt_wgrad_group_splits returns that count, for sizing ws).  ISTVT_ERR_SHAPE when a problem is not one the
+ * 256x256 bf16 weight-gradient kernel takes (N_i, K_i >= 64 and multiples of 8, 16-byte aligned rows). */
+int istvt_wgrad_group(int count, const void* const* dy, const long* lddy, const void* const* x, const long* ldx,
+                      float* const* out, const int* N, const int* K, int M, int splits, float* ws, long ws_elems,
+                      istvt_stream_t stream);
+int istvt_wgrad_group_splits(int count, const int* N, const int* K, int M);
+
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
 int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,
                         float* rstd, long M, int D, float eps, int dtype, istvt_stream_t stream);

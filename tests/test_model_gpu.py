@@ -678,3 +678,42 @@ def test_dead_row_elimination_matches_reference_golden(golden_dir):
     assert relerr(x.grad.flatten(2).norm(dim=2), g['T8.dx_frame_norms']) < 1e-3
     for k, q in mod.named_parameters():
         assert relerr(q.grad.norm(), g['T8.gnorm.' + k]) < 1e-3, k
+
+
+@pytest.mark.gpu
+def test_grouped_weight_gradients_match_ungrouped():
+    """bf16 model: the weight gradients of a layer queued and launched as one grid (functional._wgrad with group 8,
+    ops.linear_wgrad_group) against each launched on its own (group 1), on the side stream and on the main stream, step
+    after step.  The two differ only in the fp32 order of the split-K partial sums.  Also with the row-pruned last
+    layer, whose weight gradients have another row count and must form their own group."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import functional as Fn, parallel
+    R, p, x, labels, grid = _oracle_case(2, 4, 96, 2)
+    results = {}
+    try:
+        for group, overlap, dre in ((1, False, False), (8, False, False), (8, True, False), (3, True, False),
+                                    (1, False, True), (8, True, True)):
+            Fn.set_wgrad_overlap(overlap)
+            Fn.set_wgrad_group(group)
+            torch.manual_seed(0)
+            model = _hip_model(p, 4, grid, 2, torch.bfloat16)
+            model.set_dead_row_elimination(dre)
+            live = parallel.live_named_parameters(model)
+            bucket = parallel.GradBucket([q for _, q in live], fuse_accumulate=True)
+            snaps = []
+            for it in range(2):
+                bucket.zero()
+                out = model(x.cuda() * (1.0 + 0.25 * it))
+                torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), labels.cuda()).backward()
+                snaps.append(bucket.flat.clone())
+            assert not Fn._overlap['pending'] and not Fn._overlap['queue'] and not Fn._overlap['keep']
+            results[(group, overlap, dre)] = snaps
+    finally:
+        Fn.set_wgrad_overlap(True)
+        Fn.set_wgrad_group(8)
+    for key, base in (((8, False, False), (1, False, False)), ((8, True, False), (1, False, False)),
+                      ((3, True, False), (1, False, False)), ((8, True, True), (1, False, True))):
+        for a, b in zip(results[key], results[base]):
+            assert float(b.norm()) > 0
+            assert relerr(a, b) < 1e-5, key
