@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libistvt_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result', '-ffp-contract=fast'] + os.environ.get('ISTVT_EXTRA_HIPCC_FLAGS', '').split()
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result', '-Wno-inline-asm', '-ffp-contract=fast'] + os.environ.get('ISTVT_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def _sources():

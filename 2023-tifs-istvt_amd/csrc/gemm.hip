@@ -34,6 +34,7 @@ struct GemmArgs {
     float alpha;
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
     int gm;               // gemm256q: row-panels per tile group (L2 locality of the tile walk)
+    int band;             // gemm256q: > 0: column bands of this many tiles instead (wide outputs, see tile_origin)
     double* st_sum;       // gemm256q<.., STATS = 1>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
     double* st_sumsq;     //   (double[R][2][N] accumulators of stem.hip; train-mode BatchNorm statistics of a 1x1 conv)
                           // gemm256q<.., STATS = 2>: st_sum only (a bias gradient; folded by istvt_stats_reduce_add)
@@ -302,6 +303,14 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.st_sum = col_sum; a.st_sumsq = col_sumsq;
     if (col_sumsq && !col_sum) return ISTVT_ERR_SHAPE;
     a.gm = 4;             // sweep at the model's shapes: 4 row-panels per tile group is best or neutral everywhere
+    {
+        // column bands for wide outputs (tile_origin in gemm256q.h).  Measured in the model at N = 2912 (12 column tiles):
+        // bands of 6 tiles: GELU-forward GEMM 4.12 -> 3.96 ms per step, GELU-backward 4.05 -> 3.98; bands of 3: -3 % / +1.5 %;
+        // bands of 2 or 4: the plain epilogue gains 7..9 %, the two GELU epilogues lose 8..16 %.  ISTVT_GEMM_BAND overrides.
+        static const int band_env = getenv("ISTVT_GEMM_BAND") ? atoi(getenv("ISTVT_GEMM_BAND")) : 6;
+        const int tn = (N + T256 - 1) / T256;
+        a.band = tn >= 8 ? band_env : 0;
+    }
     int kper = (K + splitk - 1) / splitk;
     kper = ((kper + bk - 1) / bk) * bk;
     a.kper = kper;

@@ -41,6 +41,11 @@
 //     units <= 4kt+6, issued <= 4kt+9: 6 pieces.  Fewer exist only at the end of the stream.
 #pragma once
 
+// -DISTVT_Q_ORDER=1: the round-1 order inside a load slot (fragment reads, then the DMA issue) for A/B runs
+#ifndef ISTVT_Q_ORDER
+#define ISTVT_Q_ORDER 0
+#endif
+
 constexpr int QU_BYTES = 16384;
 constexpr int QNU = 8;
 
@@ -110,6 +115,17 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         int id = (int)blockIdx.x + i * G;
         const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
         id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+        if (p.band > 0) {
+            // Wide outputs (N = 2912: 12 column tiles, W = 4.2 MB > one XCD's L2): column bands of p.band tiles, a band's
+            // tiles row by row.  An XCD's contiguous eighth of the list then stays inside ONE band: its slice of W
+            // (3 x 373 KB) is L2-resident and an A row panel is shared by the band's column tiles running side by side.
+            const int bw = p.band, nb = (tiles_n + bw - 1) / bw;
+            const int b = min(id / (tiles_m * bw), nb - 1);
+            const int idl = id - b * tiles_m * bw, wb = min(bw, tiles_n - b * bw);
+            bm0 = (idl / wb) * TM;
+            bn0 = (b * bw + idl % wb) * T256;
+            return;
+        }
         const int gm = p.gm > 0 ? p.gm : 1;
         const int per_group = gm * tiles_n;
         const int grp = id / per_group, idl = id % per_group;
@@ -156,21 +172,17 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         const unsigned deadbit = (chunk * 8 >= p.K - k0) ? OOB : 0u;
         const int sa = a_org + k0 * 2 + (J0 == 2 ? 128 * lda * 2 : 0);
         const int sb = b_org + k0 * 2 + (J0 == 2 ? 128 * ldb * 2 : 0);
+        const unsigned dst = (unsigned)(__SIZE_TYPE__)(lds_void*)img;
         if (J0 == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + i * 8192), 16, va[i] | deadbit, sa, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(a_rs, dst + i * 8192, va[i] | deadbit, sa);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, vb[i] | deadbit, sb, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(b_rs, dst + QU_BYTES + i * 8192, vb[i] | deadbit, sb);
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + i * 8192), 16, vb[i] | deadbit, sb, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(b_rs, dst + i * 8192, vb[i] | deadbit, sb);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16,
-                                                         va[i] | deadbit | (i == 1 ? ah_dead : 0u), sa, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(a_rs, dst + QU_BYTES + i * 8192, va[i] | deadbit | (i == 1 ? ah_dead : 0u), sa);
         }
         P += 2;
         if (J0 == 2 && ++p_s == nkt) {
@@ -315,8 +327,19 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 }
             };
             // ---- phase A: AL x B
+            // The DMA of the units 6..7 ahead goes out FIRST -- its slots were released by the barrier that opened this
+            // load slot, and the loop is bound by how early these requests start -- and only then the fragment reads.
+            // Needs the opaque DMA form (dma16_lds, gemm_shared.h): after the builtin the compiler drains vmcnt before
+            // every LDS read.
             if (DBG & 64) __builtin_amdgcn_s_setprio(1);
-            if (DBG & 32) { issue_pair(2); __builtin_amdgcn_sched_barrier(0); }
+            if (first && p.bias) {
+                // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped);
+                // issued BEFORE this slot's units, so that the wait at the end of phase B covers it
+                const int col = min(bn0 + wn * 64 + lane, p.N - 1);
+                dma4_lds(__builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.bias), 0, p.N * 4, RSRC_FLAGS),
+                         (unsigned)(__SIZE_TYPE__)(lds_void*)slab, (unsigned)(col * 4), 0);
+            }
+            if (ISTVT_Q_ORDER == 0) issue_pair(2);                           // units U0+6, U0+7
             load_a(ua_lo, la_a, 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -328,13 +351,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                     bq[t][1] = *reinterpret_cast<const bf16x8*>(ub + la_b[1] + t * 2048);
                 }
             }
-            if (first && p.bias) {
-                // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped);
-                // issued BEFORE this slot's units, so that the wait at the end of phase B covers it
-                const int col = min(bn0 + wn * 64 + lane, p.N - 1);
-                __builtin_amdgcn_global_load_lds((glb_void*)(p.bias + col), (lds_void*)slab, 4, 0, 0);
-            }
-            if (!(DBG & 32)) issue_pair(2);                                  // units U0+6, U0+7
+            if (ISTVT_Q_ORDER == 1) issue_pair(2);
             // unit U0+3 (AH) landed: all but the 4 younger units (8 pieces); fewer exist only when the stream ends
             if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
@@ -344,9 +361,9 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             slot_barrier();
             // ---- phase B: AH x B
             if (DBG & 64) __builtin_amdgcn_s_setprio(1);
-            if (DBG & 32) { issue_pair(0); __builtin_amdgcn_sched_barrier(0); }
+            if (ISTVT_Q_ORDER == 0) issue_pair(0);                           // units U0+8, U0+9
             load_a(ua_hi, la_h, NB);
-            if (!(DBG & 32)) issue_pair(0);                                  // units U0+8, U0+9
+            if (ISTVT_Q_ORDER == 1) issue_pair(0);
             if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
             // units <= U0+6 (the next K tile's AL, BL, BH) landed; the side loads just issued are younger still
             if (total_u - 1 - (U0 + 6) >= 3) {

@@ -17,6 +17,16 @@
 // Phases, slots, stagger, hazards and vmcnt counts are those of gemm256q.h (two phases of 32 MFMA per K tile).
 #pragma once
 
+// -DISTVT_T_DIAG=n (diagnostic builds only, tools/build_variant.sh + tools/gemm_bench.py with GB_LIB): bit 0 drops the
+// MFMAs, bit 1 the LDS fragment reads, bit 2 the operand DMA of the K loop -- which of the three the K tile's time follows.
+// -DISTVT_T_ORDER=1: the round-1 order inside a load slot (fragment reads, then the DMA issue) for A/B runs.
+#ifndef ISTVT_T_DIAG
+#define ISTVT_T_DIAG 0
+#endif
+#ifndef ISTVT_T_ORDER
+#define ISTVT_T_ORDER 0
+#endif
+
 __device__ __forceinline__ int tswz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
 // fragment of 8 consecutive k (k0 .. k0+7) for column col16 + r out of a [64][128] unit image
@@ -33,6 +43,12 @@ __device__ __forceinline__ bf16x8 t_frag(const char* img, int k0, int col16, int
     short8v s;
     s[0] = lo[0]; s[1] = lo[1]; s[2] = lo[2]; s[3] = lo[3]; s[4] = hi[0]; s[5] = hi[1]; s[6] = hi[2]; s[7] = hi[3];
     return __builtin_bit_cast(bf16x8, s);
+}
+
+__device__ __forceinline__ bf16x8 diag_frag(int v) {
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const short x = (short)(0x3c00 | (v & 63));
+    return __builtin_bit_cast(bf16x8, short8v{x, x, x, x, x, x, x, x});
 }
 
 // Workgroup placement.  The hardware deals workgroup ids round-robin to the 8 XCDs (id & 7), each with its own L2.
@@ -86,20 +102,18 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
         const int k0 = k_begin + p_s * 64;
         const int sa = k0 * lda * 2 + (bm0 + (J0 == 2 ? 128 : 0)) * 2;
         const int sb = k0 * ldb * 2 + (bn0 + (J0 == 2 ? 128 : 0)) * 2;
+        if (ISTVT_T_DIAG & 4) { P += 2; if (J0 == 2) ++p_s; return; }
+        const unsigned dst = (unsigned)(__SIZE_TYPE__)(lds_void*)img;
         if (J0 == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + i * 8192), 16, va[i], sa, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(a_rs, dst + i * 8192, va[i], sa);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, vb[i], sb, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(b_rs, dst + QU_BYTES + i * 8192, vb[i], sb);
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(img + i * 8192), 16, vb[i], sb, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(b_rs, dst + i * 8192, vb[i], sb);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(img + QU_BYTES + i * 8192), 16, va[i], sa, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16_lds(a_rs, dst + QU_BYTES + i * 8192, va[i], sa);
         }
         P += 2;
         if (J0 == 2) ++p_s;
@@ -125,6 +139,7 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
         const char* ub = ubase + b_unit * QU_BYTES;
         bf16x8 af[4][2], bq[4][2];
         auto mma = [&](const int mt0) {
+            if (ISTVT_T_DIAG & 1) return;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -137,23 +152,30 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int kh = 0; kh < 2; ++kh) af[t][kh] = t_frag(base, kh * 32 + 8 * g, wm * 64 + t * 16, r);
+                for (int kh = 0; kh < 2; ++kh)
+                    af[t][kh] = (ISTVT_T_DIAG & 2) ? diag_frag(lane + t + kh) : t_frag(base, kh * 32 + 8 * g, wm * 64 + t * 16, r);
         };
         // ---- phase A: AL x B
+        // The DMA of the units 6..7 ahead goes out FIRST (its slots were released by the barrier that opened this load
+        // slot): the loop is bound by the latency of these requests, and issued after the fragment reads they started
+        // ~0.2 us later in every phase.  Only possible with the opaque DMA form (dma16_lds, gemm_shared.h).
+        if (ISTVT_T_ORDER == 0) issue_pair(2);                           // units U0+6, U0+7
         load_a(ua_lo);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) bq[t][kh] = t_frag(ub, kh * 32 + 8 * g, (wn & 1) * 64 + t * 16, r);
-        issue_pair(2);                                                   // units U0+6, U0+7
+            for (int kh = 0; kh < 2; ++kh)
+                bq[t][kh] = (ISTVT_T_DIAG & 2) ? diag_frag(lane - t - kh) : t_frag(ub, kh * 32 + 8 * g, (wn & 1) * 64 + t * 16, r);
+        if (ISTVT_T_ORDER == 1) issue_pair(2);
         if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
         slot_barrier();
         mma(0);
         slot_barrier();
         // ---- phase B: AH x B
+        if (ISTVT_T_ORDER == 0) issue_pair(0);                           // units U0+8, U0+9
         load_a(ua_hi);
-        issue_pair(0);                                                   // units U0+8, U0+9
+        if (ISTVT_T_ORDER == 1) issue_pair(0);
         if (total_u - 1 - (U0 + 6) >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 6)));
         slot_barrier();

@@ -32,7 +32,14 @@ def timeit(fn):
 
 
 def rnd(*s):
-    return (torch.randn(*s, device='cuda') * 0.5).to(dt)
+    """random bf16 [M, D] with line-aligned rows, as the model's activations and weight operands are (ops.empty_rows);
+    GB_DENSE=1: dense rows (what a caller with plain contiguous tensors gets: slower in the LDS-DMA GEMMs)"""
+    t = (torch.randn(*s, device='cuda') * 0.5).to(dt)
+    if os.environ.get('GB_DENSE') == '1':
+        return t
+    v = ops.empty_rows(s[0], s[1], dt, t.device, True)
+    v.copy_(t)
+    return v
 
 
 shapes = [(728, 2912), (2912, 728), (728, 1536), (512, 728), (728, 1024), (728, 512)]
@@ -40,14 +47,15 @@ for K, N in shapes:
     x, w = rnd(M, K), rnd(N, K)
     b = torch.randn(N, device='cuda')
     res = rnd(M, N)
+    pad = os.environ.get('GB_DENSE') != '1'
     fl = 2.0 * M * N * K
     if which in ('all', 'fwd'):
-        t = timeit(lambda: ops.linear_fwd(x, w))
+        t = timeit(lambda: ops.linear_fwd(x, w, pad=pad))
         print('fwd   plain    M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
-        t = timeit(lambda: ops.linear_fwd(x, w, b, res))
+        t = timeit(lambda: ops.linear_fwd(x, w, b, res, pad=pad))
         print('fwd   bias+res M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
     if which in ('all', 'gelu') and N == 2912:
-        t = timeit(lambda: ops.linear_fwd(x, w, b, gelu=True))
+        t = timeit(lambda: ops.linear_fwd(x, w, b, gelu=True, pad=pad))
         print('fwd   gelu     M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
     if which in ('all', 'wgrad'):
         dy = rnd(M, N)
