@@ -19,12 +19,12 @@ SIGNATURES = {
     'istvt_layernorm_fwd': [P, L, P, P, P, L, P, P, L, I, F, I, P],
     'istvt_layernorm_fwd_diff': [P, L, P, P, P, L, P, L, P, P, I, I, I, I, F, I, P],
     'istvt_layernorm_bwd': [P, L, P, L, P, L, P, P, P, P, L, P, L, P, P, P, L, I, I, I, I, P],
-    'istvt_attn_spatial_fwd': [P, P, P, I, I, I, I, F, I, P],
-    'istvt_attn_spatial_bwd': [P, P, P, P, P, P, I, I, I, I, F, I, P],
-    'istvt_attn_spatial_fwd_fp8': [P, P, P, I, I, I, I, F, I, P],
-    'istvt_attn_spatial_bwd_fp8': [P, P, P, P, P, P, I, I, I, I, F, I, P],
-    'istvt_attn_temporal_fwd': [P, P, P, I, I, I, I, I, F, I, P],
-    'istvt_attn_temporal_bwd': [P, P, P, P, P, I, I, I, I, I, F, I, P],
+    'istvt_attn_spatial_fwd': [P, L, P, L, P, I, I, I, I, F, I, P],
+    'istvt_attn_spatial_bwd': [P, L, P, P, L, P, P, P, I, I, I, I, F, I, P],
+    'istvt_attn_spatial_fwd_fp8': [P, L, P, L, P, I, I, I, I, F, I, P],
+    'istvt_attn_spatial_bwd_fp8': [P, L, P, P, L, P, P, P, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_fwd': [P, L, P, P, L, I, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_bwd': [P, L, P, P, P, P, L, I, I, I, I, I, F, I, P],
     'istvt_tokens_fwd': [P, P, P, P, P, L, I, I, I, I, I, I, P],
     'istvt_tokens_bwd': [P, L, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],

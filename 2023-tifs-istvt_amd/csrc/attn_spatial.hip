@@ -162,7 +162,7 @@ constexpr int RES_CHUNKS = 2;
 
 template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                        float* __restrict__ lse, int P, int heads, float scale) {
+                                                        float* __restrict__ lse, int P, int heads, float scale, long ldqkv, long ldo) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     constexpr int NIMG = RES ? RES_CHUNKS : 1;
     __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
-    const long ld = 3L * inner;
+    const long ld = ldqkv;
     const T* base = qkv + (long)bf * P * ld;
     const T* qp = base + h * DH;
     const T* kp = base + inner + h * DH;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
         if (q >= P) continue;
         const float inv = 1.0f / l_run[u];
         const float oinv = FP8 ? inv * (1.0f / P8_SCALE) : inv;
-        T* op = out + ((long)bf * P + q) * inner + h * DH;
+        T* op = out + ((long)bf * P + q) * ldo + h * DH;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             float v[4] = {o[dt][u][0] * oinv, o[dt][u][1] * oinv, o[dt][u][2] * oinv, o[dt][u][3] * oinv};
@@ -362,7 +362,7 @@ template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv, int P,
-                                                           int heads, float scale) {
+                                                           int heads, float scale, long ldqkv, long ldo) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     constexpr int NIMG = RES ? RES_CHUNKS : 1;
     __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
@@ -371,13 +371,13 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
-    const long ld = 3L * inner;
+    const long ld = ldqkv;
     const T* base = qkv + (long)bf * P * ld;
     const T* qp = base + h * DH;
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
-    const T* op = out + (long)bf * P * inner + h * DH;
-    const T* dop = dout + (long)bf * P * inner + h * DH;
+    const T* op = out + (long)bf * P * ldo + h * DH;
+    const T* dop = dout + (long)bf * P * ldo + h * DH;
     const float c = scale * LOG2E;
     constexpr int NBLK = RES ? RES_CHUNKS : 1;
     // rows of every query block this wavefront will own, requested before the staging (see sattn_fwd_kernel)
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 qf_pre[qi][u][ks] = row_frag<T>(qp, ld, q, P, 32 * ks + 8 * g);
-                dof_pre[qi][u][ks] = row_frag<T>(dop, inner, q, P, 32 * ks + 8 * g);
-                of_pre[qi][u][ks] = row_frag<T>(op, inner, q, P, 32 * ks + 8 * g);
+                dof_pre[qi][u][ks] = row_frag<T>(dop, ldo, q, P, 32 * ks + 8 * g);
+                of_pre[qi][u][ks] = row_frag<T>(op, ldo, q, P, 32 * ks + 8 * g);
             }
             st_pre[qi][u] = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
         }
@@ -517,7 +517,7 @@ template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                            int P, int heads, float scale) {
+                                                            int P, int heads, float scale, long ldqkv, long ldo) {
     constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
     constexpr int NIMG = RES ? RES_CHUNKS : 1;
     __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
@@ -527,12 +527,12 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
-    const long ld = 3L * inner;
+    const long ld = ldqkv;
     const T* base = qkv + (long)bf * P * ld;
     const T* qp = base + h * DH;
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
-    const T* dop = dout + (long)bf * P * inner + h * DH;
+    const T* dop = dout + (long)bf * P * ldo + h * DH;
     const float c = scale * LOG2E;
     constexpr int NBLK = RES ? RES_CHUNKS : 1;
     // key / value rows of every block this wavefront will own, requested before the staging (see sattn_fwd_kernel)
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                 vf_pre[ki][kt][ks] = row_frag<T>(vp, ld, key, P, 32 * ks + 8 * g);
             }
     if constexpr (RES) {                               // every query / dO row and its statistics staged once
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, (long)inner, P, tid);
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, ldo, P, tid);
         for (int q = tid; q < NIMG * CHUNK; q += 512 / U) {
             const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
             stat_s[0][q] = st.x - __builtin_amdgcn_logf(st.y);       // exponent offset incl. log2(1/sum); +inf for padding
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
     float dlreg = 0.f;
     auto fetch = [&](int c0) {
         stage_fetch(qreg, qp, ld, c0, P, tid);
-        stage_fetch(dreg, dop, (long)inner, c0, P, tid);
+        stage_fetch(dreg, dop, ldo, c0, P, tid);
         if (tid < CHUNK) {
             const int q = c0 + tid;
             streg = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h]
@@ -685,58 +685,60 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
     } while (0)
 
 // qkv: [BF*P][3*heads*dh]; out: [BF*P][heads*dh]; lse: [BF*P][heads][2] = (row max in the log2 domain, 1/rowsum)
-extern "C" int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh,
+extern "C" int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, long ldo, float* lse, int BF, int P, int heads, int dh,
                                       float scale, int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
     // bf16: 8 wavefronts x 16 queries (more wavefronts per SIMD); fp32 keeps 4 x 32 (its LDS image fills the CU)
     if (dtype == DT_BF16) {
         if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {      // one workgroup per (frame, head), keys resident (P = 197 at 224^2)
             DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, false, true>), dim3(1, BF * heads), dim3(512), 0,
-                                               stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+                                               stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale, ldqkv, ldo));
             return istvt_check_launch();
         }
         DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream,
-                                           (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+                                           (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale, ldqkv, ldo));
         return istvt_check_launch();
     }
     dim3 block(256);
     DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<T, DH, 2>), grid, block, 0, stream,
-                                                             (const T*)qkv, (T*)out, lse, P, heads, scale)));
+                                                             (const T*)qkv, (T*)out, lse, P, heads, scale, ldqkv, ldo)));
     return istvt_check_launch();
 }
 
 // delta: scratch [BF*P][heads] fp32 (written here, consumed by the dK/dV kernel); dqkv: [BF*P][3*inner]
-extern "C" int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+extern "C" int istvt_attn_spatial_bwd(const void* qkv, long ldqkv, const void* out, const void* dout, long ldo, const float* lse,
                                       float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale,
                                       int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
     if (dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
         const dim3 g1(1, BF * heads);
         DISPATCH_DH(dh, {
             hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
             hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, false, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
         });
         return istvt_check_launch();
     }
     if (dtype == DT_BF16) {                     // 8 wavefronts x 16 rows, see sattn_fwd_kernel
         DISPATCH_DH(dh, {
             hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
             hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
         });
         return istvt_check_launch();
     }
     dim3 block(256);
     DISPATCH_DTYPE(dtype, DISPATCH_DH(dh, {
         hipLaunchKernelGGL((sattn_bwd_dq_kernel<T, DH, 2>), grid, block, 0, stream, (const T*)qkv, (const T*)out,
-                           (const T*)dout, lse, delta, (T*)dqkv, P, heads, scale);
+                           (const T*)dout, lse, delta, (T*)dqkv, P, heads, scale, ldqkv, ldo);
         hipLaunchKernelGGL((sattn_bwd_dkv_kernel<T, DH, 2>), grid, block, 0, stream, (const T*)qkv, (const T*)dout, lse,
-                           (const float*)delta, (T*)dqkv, P, heads, scale);
+                           (const float*)delta, (T*)dqkv, P, heads, scale, ldqkv, ldo);
     }));
     return istvt_check_launch();
 }
@@ -744,42 +746,44 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, const void* out, const vo
 // ---- fp8 variant (bfloat16 storage only): Q, K, V and the probabilities enter the attention MFMAs as OCP e4m3
 // (v_mfma_f32_16x16x32_fp8_fp8); softmax, statistics, accumulation and every other product stay as above.  The
 // backward recomputes S with the same fp8 operands, so the saved (max, 1/sum) match its probabilities.
-extern "C" int istvt_attn_spatial_fwd_fp8(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh,
+extern "C" int istvt_attn_spatial_fwd_fp8(const void* qkv, long ldqkv, void* out, long ldo, float* lse, int BF, int P, int heads, int dh,
                                           float scale, int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
     if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
         DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true, true>), dim3(1, BF * heads), dim3(512), 0,
-                                           stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+                                           stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale, ldqkv, ldo));
         return istvt_check_launch();
     }
     DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream,
-                                       (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale));
+                                       (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale, ldqkv, ldo));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse,
+extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const void* out, const void* dout, long ldo, const float* lse,
                                           float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale,
                                           int dtype, hipStream_t stream) {
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
     if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
         const dim3 g1(1, BF * heads);
         DISPATCH_DH(dh, {
             hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
             hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
         });
         return istvt_check_launch();
     }
     DISPATCH_DH(dh, {
         hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
-                           (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale);
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
         hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream, (const bf16_t*)qkv,
-                           (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale);
+                           (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
     });
     return istvt_check_launch();
 }

@@ -39,7 +39,7 @@ __device__ __forceinline__ float dot4(const float (&a)[4], const float (&b)[4]) 
 template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         T* __restrict__ out, int B, int F, int P, int heads,
-                                                        float scale) {
+                                                        float scale, long ldqk, long ldv) {
     constexpr int CL = DH / 4, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
     for (int f = 0; f < FMAX; ++f) {
         if (f < F) {
             const long m = row0 + (long)f * P;
-            load4(qk + m * 2 * inner + col, q[f]);
-            load4(qk + m * 2 * inner + inner + col, k[f]);
-            load4(v + m * inner + col, vv[f]);
+            load4(qk + m * ldqk + col, q[f]);
+            load4(qk + m * ldqk + inner + col, k[f]);
+            load4(v + m * ldv + col, vv[f]);
         }
     }
 #pragma unroll
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
             }
             if (valid) {
                 const long m = row0 + (long)i * P;
-                store4(out + m * inner + col, o);
+                store4(out + m * ldv + col, o);
             }
         }
     }
@@ -119,7 +119,7 @@ template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         const T* __restrict__ dout, T* __restrict__ dqk,
                                                         T* __restrict__ dv, int B, int F, int P, int heads,
-                                                        float scale) {
+                                                        float scale, long ldqk, long ldv) {
     constexpr int CL = DH / 4, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
     for (int f = 0; f < FMAX; ++f) {
         if (f < F) {
             const long m = row0 + (long)f * P;
-            load4(qk + m * 2 * inner + col, q[f]);
-            load4(qk + m * 2 * inner + inner + col, k[f]);
-            load4(v + m * inner + col, vv[f]);
-            load4(dout + m * inner + col, dO[f]);
+            load4(qk + m * ldqk + col, q[f]);
+            load4(qk + m * ldqk + inner + col, k[f]);
+            load4(v + m * ldv + col, vv[f]);
+            load4(dout + m * ldv + col, dO[f]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { dk[f][e] = 0.f; dvv[f][e] = 0.f; }
         }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
                     }
                 }
             }
-            if (valid) store4(dqk + m * 2 * inner + col, dq);
+            if (valid) store4(dqk + m * ldqk + col, dq);
         }
     }
     if (valid) {
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
         for (int f = 0; f < FMAX; ++f) {
             if (f < F) {
                 const long m = row0 + (long)f * P;
-                store4(dqk + m * 2 * inner + inner + col, dk[f]);
-                store4(dv + m * inner + col, dvv[f]);
+                store4(dqk + m * ldqk + inner + col, dk[f]);
+                store4(dv + m * ldv + col, dvv[f]);
             }
         }
     }
@@ -246,7 +246,7 @@ template <int EPL> __device__ __forceinline__ float dotE(const float (&a)[EPL], 
 template <typename T, int DH, int FMAX, int EPL>
 __global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         T* __restrict__ out, int B, int F, int P, int heads,
-                                                        float scale) {
+                                                        float scale, long ldqk, long ldv) {
     constexpr int CL = DH / EPL, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -266,19 +266,19 @@ __global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ q
     for (int f = 0; f < FMAX; ++f) {
         if (f < F) {
             const long m = row0 + (long)f * P;
-            loadE<EPL>(qk + m * 2 * inner + inner + col, k[f]);
-            loadE<EPL>(v + m * inner + col, vv[f]);
+            loadE<EPL>(qk + m * ldqk + inner + col, k[f]);
+            loadE<EPL>(v + m * ldv + col, vv[f]);
         }
     }
     float qn[EPL];
-    loadE<EPL>(qk + row0 * 2 * inner + col, qn);
+    loadE<EPL>(qk + row0 * ldqk + col, qn);
 #pragma unroll
     for (int i = 0; i < FMAX; ++i) {
         if (i < F) {
             float q[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) q[e] = qn[e];
-            if (i + 1 < F) loadE<EPL>(qk + (row0 + (long)(i + 1) * P) * 2 * inner + col, qn);     // one frame ahead
+            if (i + 1 < F) loadE<EPL>(qk + (row0 + (long)(i + 1) * P) * ldqk + col, qn);     // one frame ahead
             float s[FMAX];
             float mx = -INFINITY;
 #pragma unroll
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ q
             }
             if (valid) {
                 const long m = row0 + (long)i * P;
-                storeE<EPL>(out + m * inner + col, o);
+                storeE<EPL>(out + m * ldv + col, o);
             }
         }
     }
@@ -319,7 +319,7 @@ template <typename T, int DH, int FMAX, int EPL, bool HOLD = false>
 __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         const T* __restrict__ dout, T* __restrict__ dqk,
                                                         T* __restrict__ dv, int B, int F, int P, int heads,
-                                                        float scale) {
+                                                        float scale, long ldqk, long ldv) {
     constexpr int CL = DH / EPL, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
     for (int f = 0; f < FMAX; ++f) {
         if (f < F) {
             const long m = row0 + (long)f * P;
-            loadE<EPL>(qk + m * 2 * inner + inner + col, k[f]);
-            loadE<EPL>(v + m * inner + col, vv[f]);
+            loadE<EPL>(qk + m * ldqk + inner + col, k[f]);
+            loadE<EPL>(v + m * ldv + col, vv[f]);
 #pragma unroll
             for (int e = 0; e < EPL; ++e) { dk[f][e] = 0.f; dvv[f][e] = 0.f; }
         }
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
 #pragma unroll
         for (int f = 0; f < NH; ++f) {
             if (f < F) {
-                loadE<EPL>(qk + (row0 + (long)f * P) * 2 * inner + col, qa[f]);
-                loadE<EPL>(dout + (row0 + (long)f * P) * inner + col, da[f]);
+                loadE<EPL>(qk + (row0 + (long)f * P) * ldqk + col, qa[f]);
+                loadE<EPL>(dout + (row0 + (long)f * P) * ldv + col, da[f]);
             }
         }
     } else {
-        loadE<EPL>(qk + row0 * 2 * inner + col, qn);
-        loadE<EPL>(dout + row0 * inner + col, don);
+        loadE<EPL>(qk + row0 * ldqk + col, qn);
+        loadE<EPL>(dout + row0 * ldv + col, don);
     }
 #pragma unroll
     for (int i = 0; i < FMAX; ++i) {
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) { q[e] = qn[e]; dO[e] = don[e]; }
                 if (i + 1 < F) {                                               // one frame ahead
-                    loadE<EPL>(qk + (m + P) * 2 * inner + col, qn);
-                    loadE<EPL>(dout + (m + P) * inner + col, don);
+                    loadE<EPL>(qk + (m + P) * ldqk + col, qn);
+                    loadE<EPL>(dout + (m + P) * ldv + col, don);
                 }
             }
             // probabilities are recomputed exactly as the forward computes them (max, exp, sum,
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
                     }
                 }
             }
-            if (valid) storeE<EPL>(dqk + m * 2 * inner + col, dq);
+            if (valid) storeE<EPL>(dqk + m * ldqk + col, dq);
         }
     }
     if (valid) {
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
         for (int f = 0; f < FMAX; ++f) {
             if (f < F) {
                 const long m = row0 + (long)f * P;
-                storeE<EPL>(dqk + m * 2 * inner + inner + col, dk[f]);
-                storeE<EPL>(dv + m * inner + col, dvv[f]);
+                storeE<EPL>(dqk + m * ldqk + inner + col, dk[f]);
+                storeE<EPL>(dv + m * ldv + col, dvv[f]);
             }
         }
     }
@@ -443,27 +443,30 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
         else return ISTVT_ERR_SHAPE;                                                                     \
     } while (0)
 
-extern "C" int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, int B, int F, int P, int heads,
-                                       int dh, float scale, int dtype, hipStream_t stream) {
+extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, void* out, long ldv, int B, int F,
+                                       int P, int heads, int dh, float scale, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldqk % 8 || ldv % 8) return ISTVT_ERR_SHAPE;
     static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
     if (use_mfma && dtype == DT_BF16 && F <= 32 && (dh == 64 || dh == 32)) {     // one wavefront per (b, p, h), MFMA tiles
         const long nprob = (long)B * P * heads;
         dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
-#define TATTN_F(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale)
+#define TATTN_F(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale, ldqk, ldv)
         if (dh == 64) { if (F <= 16) TATTN_F(64, 1); else TATTN_F(64, 2); }
         else { if (F <= 16) TATTN_F(32, 1); else TATTN_F(32, 2); }
 #undef TATTN_F
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, tattn_fwd2_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P,
-                                         heads, scale));
+                                         heads, scale, ldqk, ldv));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int B,
-                                       int F, int P, int heads, int dh, float scale, int dtype, hipStream_t stream) {
+extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, const void* dout, void* dqk, void* dv,
+                                       long ldv, int B, int F, int P, int heads, int dh, float scale, int dtype,
+                                       hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldqk % 8 || ldv % 8) return ISTVT_ERR_SHAPE;
     static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
     // measured at C2 / C4 (tools/tattn_bench.py): F = 9 lane-cluster 170 us vs MFMA 203 us (its three 32-row LDS images
     // allow 8 wavefronts per CU); F = 17 850 us vs 336 us
@@ -474,13 +477,13 @@ extern "C" int istvt_attn_temporal_bwd(const void* qk, const void* v, const void
         const long resident = 256L * (F <= 16 ? 4 : 2);      // workgroups per CU by registers (105 / 213 VGPRs at dh 64)
         if (nwg > resident) nwg = resident;                   // wavefronts loop over problems
         dim3 grid((unsigned)nwg), block(256);
-#define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale)
+#define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale, ldqk, ldv)
         if (dh == 64) { if (F <= 16) TATTN_B(64, 1); else TATTN_B(64, 2); }
         else { if (F <= 16) TATTN_B(32, 1); else TATTN_B(32, 2); }
 #undef TATTN_B
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, tattn_bwd2_kernel, (const T*)qk, (const T*)v, (const T*)dout,
-                                         (T*)dqk, (T*)dv, B, F, P, heads, scale));
+                                         (T*)dqk, (T*)dv, B, F, P, heads, scale, ldqk, ldv));
     return istvt_check_launch();
 }

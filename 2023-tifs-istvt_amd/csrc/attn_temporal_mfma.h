@@ -90,7 +90,7 @@ __device__ __forceinline__ void stage32(bf16_t* img, const bf16_t* __restrict__ 
 template <int DH, int NTL>
 __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              bf16_t* __restrict__ out, int B, int F, int P, int heads,
-                                                             float scale) {
+                                                             float scale, long ldqk, long ldv) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][16 * NTL * LDI];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
@@ -100,11 +100,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     const long bp = prob / heads, b = bp / P, p = bp % P;
     const int inner = heads * DH;
     const long row0 = b * F * P + p;
-    const long sq = (long)P * 2 * inner, sv = (long)P * inner;
-    const bf16_t* qp = qk + row0 * 2 * inner + h * DH;
+    const long sq = (long)P * ldqk, sv = (long)P * ldv;
+    const bf16_t* qp = qk + row0 * ldqk + h * DH;
     const bf16_t* kp = qp + inner;
-    const bf16_t* vp = v + row0 * inner + h * DH;
-    bf16_t* op = out + row0 * inner + h * DH;
+    const bf16_t* vp = v + row0 * ldv + h * DH;
+    bf16_t* op = out + row0 * ldv + h * DH;
     bf16_t* Vimg = smem[wave];
     const float c = scale * TM_LOG2E;
 
@@ -169,7 +169,7 @@ template <int DH, int NTL>
 __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqk,
                                                              bf16_t* __restrict__ dv, int B, int F, int P, int heads,
-                                                             float scale) {
+                                                             float scale, long ldqk, long ldv) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
     constexpr int IMG = 16 * NTL * LDI;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * IMG];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     long prob = (long)blockIdx.x * 4 + wave;
     if (prob >= total) return;                            // no workgroup-level synchronisation below
     const int inner = heads * DH;
-    const long sq = (long)P * 2 * inner, sv = (long)P * inner;
+    const long sq = (long)P * ldqk, sv = (long)P * ldv;
     bf16_t* Qimg = smem[wave];
     bf16_t* Kimg = Qimg + IMG;
     bf16_t* Dimg = Kimg + IMG;
@@ -194,10 +194,10 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         const int h = (int)(pr % heads);
         const long bp = pr / heads, b = bp / P, pp = bp % P;
         const long row0 = b * F * P + pp;
-        const bf16_t* qp = qk + row0 * 2 * inner + h * DH;
+        const bf16_t* qp = qk + row0 * ldqk + h * DH;
         const bf16_t* kp = qp + inner;
-        const bf16_t* vp = v + row0 * inner + h * DH;
-        const bf16_t* dop = dout + row0 * inner + h * DH;
+        const bf16_t* vp = v + row0 * ldv + h * DH;
+        const bf16_t* dop = dout + row0 * ldv + h * DH;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     const int h = (int)(prob % heads);
     const long bp = prob / heads, b = bp / P, p = bp % P;
     const long row0 = b * F * P + p;
-    bf16_t* dqp = dqk + row0 * 2 * inner + h * DH;
+    bf16_t* dqp = dqk + row0 * ldqk + h * DH;
     bf16_t* dkp = dqp + inner;
-    bf16_t* dvp = dv + row0 * inner + h * DH;
+    bf16_t* dvp = dv + row0 * ldv + h * DH;
     tmf::wave_lds_fence();                                // the previous problem's image reads are done
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {

@@ -23,6 +23,10 @@
 #ifndef ISTVT_T_DIAG
 #define ISTVT_T_DIAG 0
 #endif
+// -DISTVT_T_RING10=0: the 8-unit LDS ring of round 1 (two K tiles) instead of 10 units (two and a half)
+#ifndef ISTVT_T_RING10
+#define ISTVT_T_RING10 1
+#endif
 #ifndef ISTVT_T_ORDER
 #define ISTVT_T_ORDER 0
 #endif
@@ -61,7 +65,14 @@ __device__ __forceinline__ bf16x8 diag_frag(int v) {
 // One (tile, reduction split) of problem p: wg = the tile's index (row-major over the 256x256 output tiles), z = the
 // reduction split.
 __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, const int z) {
-    __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
+    // The ring: TNP slots of one unit PAIR each ((AL, BL) or (BH, AH): 32 KiB).  The K loop is bound by the latency of
+    // the operand DMA times the bytes the ring lets be in flight, and the LDS is full -- so the epilogue staging (which
+    // the K loop never touches: one tile per workgroup) aliases the ring and the ring gets a fifth slot: the producer
+    // runs 8..11 units ahead of the consumer instead of 6..9.  Five is not a power of two: slot indices are counters
+    // that wrap, the two pair bases of a K tile are scalars.
+    constexpr bool R10 = ISTVT_T_RING10 != 0;
+    constexpr int TNP = R10 ? 5 : 4;
+    __shared__ __attribute__((aligned(16))) char smem[TNP * 2 * QU_BYTES + (R10 ? 0 : 8 * PSLAB_BYTES)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r = lane & 15;
@@ -95,10 +106,11 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
     }
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.A), 0, k_end * lda * 2, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.B), 0, k_end * ldb * 2, RSRC_FLAGS);
-    int P = 0, p_s = 0;
+    int P = 0, p_s = 0, pp = 0;                         // pp: the producer's pair slot
     auto issue_pair = [&](const int J0) {              // J0 = 0 -> (AL, BL), J0 = 2 -> (BH, AH) of K tile p_s
         if (P >= total_u) return;
-        char* img = smem + (P & (QNU - 1)) * QU_BYTES + wave * 1024;
+        char* img = smem + pp * (2 * QU_BYTES) + wave * 1024;
+        pp = pp + 1 == TNP ? 0 : pp + 1;
         const int k0 = k_begin + p_s * 64;
         const int sa = k0 * lda * 2 + (bm0 + (J0 == 2 ? 128 : 0)) * 2;
         const int sb = k0 * ldb * 2 + (bn0 + (J0 == 2 ? 128 : 0)) * 2;
@@ -119,7 +131,8 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
         if (J0 == 2) ++p_s;
     };
     issue_pair(0); issue_pair(2); issue_pair(0);           // units 0..5
-    wait_vm_n(min(6, 2 * max(0, total_u - 3)));            // units 0..2 landed (own pieces)
+    if (R10) issue_pair(2);                                // .. 7
+    wait_vm_n(min(R10 ? 10 : 6, 2 * max(0, total_u - 3))); // units 0..2 landed (own pieces)
     slot_barrier();
 
     f32x4 acc[8][4];
@@ -127,16 +140,16 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int b_unit = 1 + (wn >> 1);
-    int U0 = 0;
+    int U0 = 0, c0 = 0, c1 = 1;                 // c0 / c1: pair slots of the current K tile's (AL, BL) / (BH, AH)
 
     if (wm == 1) slot_barrier();               // stagger: waves 4..7 run one slot behind
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const char* ubase = smem + (kt & 1) * 4 * QU_BYTES;
-        const char* ua_lo = ubase;
-        const char* ua_hi = ubase + 3 * QU_BYTES;
-        const char* ub = ubase + b_unit * QU_BYTES;
+        const char* ua_lo = smem + c0 * (2 * QU_BYTES);
+        const char* ua_hi = smem + c1 * (2 * QU_BYTES) + QU_BYTES;
+        const char* ub = (wn >> 1) ? smem + c1 * (2 * QU_BYTES) : ua_lo + QU_BYTES;
+        c0 = c0 + 2 >= TNP ? c0 + 2 - TNP : c0 + 2;
+        c1 = c1 + 2 >= TNP ? c1 + 2 - TNP : c1 + 2;
         bf16x8 af[4][2], bq[4][2];
         auto mma = [&](const int mt0) {
             if (ISTVT_T_DIAG & 1) return;
@@ -159,24 +172,26 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
         // The DMA of the units 6..7 ahead goes out FIRST (its slots were released by the barrier that opened this load
         // slot): the loop is bound by the latency of these requests, and issued after the fragment reads they started
         // ~0.2 us later in every phase.  Only possible with the opaque DMA form (dma16_lds, gemm_shared.h).
-        if (ISTVT_T_ORDER == 0) issue_pair(2);                           // units U0+6, U0+7
+        if (ISTVT_T_ORDER == 0) issue_pair(R10 ? 0 : 2);                 // units U0+6, U0+7 (ring of 10: U0+8, U0+9)
         load_a(ua_lo);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
                 bq[t][kh] = (ISTVT_T_DIAG & 2) ? diag_frag(lane - t - kh) : t_frag(ub, kh * 32 + 8 * g, (wn & 1) * 64 + t * 16, r);
-        if (ISTVT_T_ORDER == 1) issue_pair(2);
-        if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (ISTVT_T_ORDER == 1) issue_pair(R10 ? 0 : 2);
+        // unit U0+3 (AH) landed: all but the younger units' pieces (4 units, 6 with the ring of 10)
+        if (total_u - 1 - (U0 + 3) >= (R10 ? 6 : 4)) wait_vm_n(R10 ? 12 : 8);
         else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
         slot_barrier();
         mma(0);
         slot_barrier();
         // ---- phase B: AH x B
-        if (ISTVT_T_ORDER == 0) issue_pair(0);                           // units U0+8, U0+9
+        if (ISTVT_T_ORDER == 0) issue_pair(R10 ? 2 : 0);                 // units U0+8, U0+9 (ring of 10: U0+10, U0+11)
         load_a(ua_hi);
-        if (ISTVT_T_ORDER == 1) issue_pair(0);
-        if (total_u - 1 - (U0 + 6) >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (ISTVT_T_ORDER == 1) issue_pair(R10 ? 2 : 0);
+        // units <= U0+6 (the next K tile's AL, BL, BH) landed
+        if (total_u - 1 - (U0 + 6) >= (R10 ? 5 : 3)) wait_vm_n(R10 ? 10 : 6);
         else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 6)));
         slot_barrier();
         mma(4);
@@ -186,7 +201,9 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
     if (wm == 0) slot_barrier();               // re-align the two groups
 
     // ---- epilogue: fp32 partial tile, wave-local 16-row passes through this wave's slab -----------------
-    float* slab = reinterpret_cast<float*>(smem + QNU * QU_BYTES + wave * PSLAB_BYTES);
+    // (ring of 10: the slabs alias the ring -- every unit issued has been consumed and the re-aligning barrier above
+    //  is behind every wavefront's last fragment read)
+    float* slab = reinterpret_cast<float*>(smem + (R10 ? 0 : QNU * QU_BYTES) + wave * PSLAB_BYTES);
     const float alpha = p.alpha;
     const int colc = (lane & 7) * 8, erow = lane >> 3;
     const int row_w = wm * 64 + erow, col_w = wn * 64 + colc;

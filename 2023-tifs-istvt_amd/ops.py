@@ -55,8 +55,15 @@ def _stream() -> int:
 ROW_ALIGN = 64
 
 
+_PAD_MOD = tuple(int(v) for v in os.environ.get('ISTVT_PAD_MOD', '2,1').split(','))   # (m, r): lines per row = r mod m
+
+
 def pad_ld(n: int) -> int:
-    return (n + ROW_ALIGN - 1) // ROW_ALIGN * ROW_ALIGN
+    q = (n + ROW_ALIGN - 1) // ROW_ALIGN
+    m, r = _PAD_MOD
+    while q % m != r:
+        q += 1
+    return q * ROW_ALIGN
 
 
 def empty_rows(M: int, D: int, dtype, device, pad: bool = True) -> Tensor:
@@ -511,57 +518,77 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
 
 
 # ------------------------------------------------------------------------------------------
+def _same_rows(like: Tensor, ld: int, M: int, D: int) -> Tensor:
+    """an uninitialised [M, D] tensor with row stride ld (the layout of a saved operand: its gradient shares it)"""
+    buf = torch.empty((M, ld), dtype=like.dtype, device=like.device)
+    return buf if ld == D else buf[:, :D]
+
+
 def attn_spatial_fwd(qkv: Tensor, BF: int, P: int, heads: int, dh: int, fp8: bool = False):
-    qkv = _c(_req(qkv))
+    """qkv [BF*P, 3*heads*dh] (row-strided views allowed) -> out [BF*P, heads*dh] with line-aligned rows, lse"""
     inner = heads * dh
-    if qkv.numel() != BF * P * 3 * inner:
+    qkv, ldq = rows(_req(qkv))
+    if tuple(qkv.shape) != (BF * P, 3 * inner):
         raise RuntimeError('attn_spatial: qkv %s is not (%d*%d, 3*%d)' % (tuple(qkv.shape), BF, P, inner))
-    out = torch.empty((BF * P, inner), dtype=qkv.dtype, device=qkv.device)
+    out = empty_rows(BF * P, inner, qkv.dtype, qkv.device)
     lse = torch.empty((BF * P, heads, 2), dtype=torch.float32, device=qkv.device)   # (row max [log2], 1/rowsum)
     if fp8 and qkv.dtype != torch.bfloat16:
         raise TypeError('the fp8 attention path needs bfloat16 activations')
     fn = _lib.lib().istvt_attn_spatial_fwd_fp8 if fp8 else _lib.lib().istvt_attn_spatial_fwd
     with prof('attn_spatial_fwd', 4 * BF * P * inner * qkv.element_size(), 4.0 * BF * heads * P * P * dh):
-        _lib.check(fn(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), BF, P, heads, dh, dh ** -0.5, dtype_code(qkv),
-                      _stream()), 'istvt_attn_spatial_fwd')
+        _lib.check(fn(qkv.data_ptr(), ldq, out.data_ptr(), out.stride(0), lse.data_ptr(), BF, P, heads, dh, dh ** -0.5,
+                      dtype_code(qkv), _stream()), 'istvt_attn_spatial_fwd')
     return out, lse
 
 
 def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: int, P: int, heads: int, dh: int,
                      fp8: bool = False) -> Tensor:
-    dout = _c(_req(dout))
-    dqkv = torch.empty_like(qkv)
-    delta = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
     inner = heads * dh
+    qkv, ldq = rows(_req(qkv))
+    out, ldo = rows(_req(out))
+    dout, ldd = rows(_req(dout))
+    if ldd != ldo:                       # the kernels take one stride for out and dout
+        d2 = _same_rows(out, ldo, BF * P, inner)
+        d2.copy_(dout)
+        dout = d2
+    dqkv = _same_rows(qkv, ldq, BF * P, 3 * inner)
+    delta = torch.empty((BF * P, heads), dtype=torch.float32, device=qkv.device)
     fn = _lib.lib().istvt_attn_spatial_bwd_fp8 if fp8 else _lib.lib().istvt_attn_spatial_bwd
     with prof('attn_spatial_bwd', 8 * BF * P * inner * qkv.element_size(), 10.0 * BF * heads * P * P * dh):
-        _lib.check(fn(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
-                      BF, P, heads, dh, dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
+        _lib.check(fn(qkv.data_ptr(), ldq, out.data_ptr(), dout.data_ptr(), ldo, lse.data_ptr(), delta.data_ptr(),
+                      dqkv.data_ptr(), BF, P, heads, dh, dh ** -0.5, dtype_code(qkv), _stream()), 'istvt_attn_spatial_bwd')
     return dqkv
 
 
 def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int, dh: int):
-    qk, v = _c(_req(qk)), _c(_req(v))
+    """qk [B*F*P, 2*heads*dh], v [B*F*P, heads*dh] (row-strided views allowed) -> out with v's row stride"""
     inner = heads * dh
+    (qk, ldqk), (v, ldv) = rows(_req(qk)), rows(_req(v))
     if F > 17:
         raise RuntimeError('attn_temporal: at most 17 frames (T <= 16) are supported, got F=%d' % F)
-    if qk.numel() != B * F * P * 2 * inner or v.numel() != B * F * P * inner:
+    if tuple(qk.shape) != (B * F * P, 2 * inner) or tuple(v.shape) != (B * F * P, inner):
         raise RuntimeError('attn_temporal: shapes %s / %s do not match B=%d F=%d P=%d' % (tuple(qk.shape), tuple(v.shape), B, F, P))
-    out = torch.empty((B * F * P, inner), dtype=qk.dtype, device=qk.device)
+    out = _same_rows(v, ldv, B * F * P, inner)
     with prof('attn_temporal_fwd', 4 * B * F * P * inner * qk.element_size(), 4.0 * B * P * heads * F * F * dh):
-        _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), v.data_ptr(), out.data_ptr(), B, F, P,
+        _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), ldqk, v.data_ptr(), out.data_ptr(), ldv, B, F, P,
                                                       heads, dh, dh ** -0.5, dtype_code(qk), _stream()),
                    'istvt_attn_temporal_fwd')
     return out
 
 
 def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: int, heads: int, dh: int):
-    dout = _c(_req(dout))
-    dqk = torch.empty_like(qk)
-    dv = torch.empty_like(v)
+    inner = heads * dh
+    (qk, ldqk), (v, ldv) = rows(_req(qk)), rows(_req(v))
+    dout, ldd = rows(_req(dout))
+    if ldd != ldv:                       # the kernels take one stride for v, dout and dv
+        d2 = _same_rows(v, ldv, B * F * P, inner)
+        d2.copy_(dout)
+        dout = d2
+    dqk = _same_rows(qk, ldqk, B * F * P, 2 * inner)
+    dv = _same_rows(v, ldv, B * F * P, inner)
     with prof('attn_temporal_bwd', 7 * B * F * P * heads * dh * qk.element_size(), 10.0 * B * P * heads * F * F * dh):
-        _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), v.data_ptr(), dout.data_ptr(),
-                                                      dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
+        _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), ldqk, v.data_ptr(), dout.data_ptr(),
+                                                      dqk.data_ptr(), dv.data_ptr(), ldv, B, F, P, heads, dh, dh ** -0.5,
                                                       dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
     return dqk, dv
 

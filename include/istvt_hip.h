@@ -90,28 +90,31 @@ int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, long ld_dy2
                         int dtype, istvt_stream_t stream);
 
 /* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
- * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)'), out [BF*P][heads*dh],
- * lse [BF*P][heads][2] = softmax statistics (row max in the log2 domain, 1/row sum). */
-int istvt_attn_spatial_fwd(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh, float scale,
-                           int dtype, istvt_stream_t stream);
-int istvt_attn_spatial_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta_scratch,
-                           void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
+ * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)') with row stride ldqkv (elements; also dqkv's), out / dout
+ * [BF*P][heads*dh] with row stride ldo; lse [BF*P][heads][2] = softmax statistics (row max in the log2 domain,
+ * 1/row sum).  Row strides are multiples of 8 elements; line-aligned, odd-line-count rows (ops.pad_ld) are what the
+ * GEMMs on either side want. */
+int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, long ldo, float* lse, int BF, int P, int heads,
+                           int dh, float scale, int dtype, istvt_stream_t stream);
+int istvt_attn_spatial_bwd(const void* qkv, long ldqkv, const void* out, const void* dout, long ldo, const float* lse,
+                           float* delta_scratch, void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
                            istvt_stream_t stream);
 /* fp8 variant of the two entry points above (BASELINE.json configs[4]; bfloat16 storage only): Q, K, V and the
  * softmax probabilities enter the attention MFMAs as OCP e4m3 (v_mfma_f32_16x16x32_fp8_fp8); softmax, statistics,
  * accumulation and the remaining backward products are unchanged.  Same arguments. */
-int istvt_attn_spatial_fwd_fp8(const void* qkv, void* out, float* lse, int BF, int P, int heads, int dh, float scale,
-                               int dtype, istvt_stream_t stream);
-int istvt_attn_spatial_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
-                               void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
+int istvt_attn_spatial_fwd_fp8(const void* qkv, long ldqkv, void* out, long ldo, float* lse, int BF, int P, int heads,
+                               int dh, float scale, int dtype, istvt_stream_t stream);
+int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const void* out, const void* dout, long ldo, const float* lse,
+                               float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
                                istvt_stream_t stream);
 
 /* ---- temporal attention (TemporalResidualAttention.forward core, module.py:197-205) --------
- * qk [B*F*P][2*heads*dh] (q|k), v/out [B*F*P][heads*dh], rows (b,f,p); F <= 17. */
-int istvt_attn_temporal_fwd(const void* qk, const void* v, void* out, int B, int F, int P, int heads, int dh,
-                            float scale, int dtype, istvt_stream_t stream);
-int istvt_attn_temporal_bwd(const void* qk, const void* v, const void* dout, void* dqk, void* dv, int B, int F, int P,
-                            int heads, int dh, float scale, int dtype, istvt_stream_t stream);
+ * qk [B*F*P][2*heads*dh] (q|k) with row stride ldqk (also dqk's); v / out / dout / dv [B*F*P][heads*dh] with row
+ * stride ldv; rows (b,f,p); F <= 17 (float32), <= 32 (bfloat16). */
+int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, void* out, long ldv, int B, int F, int P, int heads,
+                            int dh, float scale, int dtype, istvt_stream_t stream);
+int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, const void* dout, void* dqk, void* dv, long ldv,
+                            int B, int F, int P, int heads, int dh, float scale, int dtype, istvt_stream_t stream);
 
 /* ---- token assembly (DSTTr.forward, vivit.py:133-142) -------------------------------------- */
 int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, long ldx,

@@ -189,16 +189,20 @@ def _attn_ref(q, k, v):
     return s.softmax(-1) @ v
 
 
-def attn_spatial(dtype, BF=3, P=197, heads=8, dh=64):
+def attn_spatial(dtype, BF=3, P=197, heads=8, dh=64, pad=False):
+    """pad: the operands are views of buffers with wider rows whose pad columns hold NaN (the model's layout); the
+    results come back with padded rows too and are compared as values"""
     inner = heads * dh
     qkv = rnd((BF * P, 3 * inner), dtype, 1)
+    if pad:
+        qkv = padded(qkv)
     out, lse = ops.attn_spatial_fwd(qkv, BF, P, heads, dh)
     qd = qkv.double().requires_grad_(True)
     q, k, v = (t.view(BF, P, heads, dh).transpose(1, 2) for t in qd.chunk(3, dim=-1))
     ref = _attn_ref(q, k, v).transpose(1, 2).reshape(BF * P, inner)
     dout = rnd((BF * P, inner), dtype, 2)
     ref.backward(dout.double())
-    dqkv = ops.attn_spatial_bwd(qkv, out, dout, lse, BF, P, heads, dh)
+    dqkv = ops.attn_spatial_bwd(qkv, out, padded(dout) if pad else dout, lse, BF, P, heads, dh)
     e_f = relerr(out, ref)
     e_b = max(relerr(a, b) for a, b in zip(dqkv.chunk(3, dim=-1), qd.grad.chunk(3, dim=-1)))
     return max(e_f, e_b), TOL[dtype]
@@ -227,10 +231,12 @@ def attn_spatial_fp8(BF=3, P=197, heads=8, dh=64):
     return max(e_f, e_b), 8e-2
 
 
-def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64):
+def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64, pad=False):
     inner = heads * dh
     M = B * F * P
     qk, v = rnd((M, 2 * inner), dtype, 1), rnd((M, inner), dtype, 2)
+    if pad:
+        qk, v = padded(qk), padded(v)
     out = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
     qkd, vd = qk.double().requires_grad_(True), v.double().requires_grad_(True)
 
@@ -240,7 +246,7 @@ def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64):
     ref = _attn_ref(q, k, split(vd)).permute(0, 3, 2, 1, 4).reshape(M, inner)
     dout = rnd((M, inner), dtype, 3)
     ref.backward(dout.double())
-    dqk, dv = ops.attn_temporal_bwd(qk, v, dout, B, F, P, heads, dh)
+    dqk, dv = ops.attn_temporal_bwd(qk, v, padded(dout) if pad else dout, B, F, P, heads, dh)
     e = max(relerr(out, ref), relerr(dqk, qkd.grad), relerr(dv, vd.grad))
     return e, TOL[dtype]
 
@@ -897,4 +903,19 @@ def all_checks():  # noqa: F811
     out.append(('wgrad_group_three_M1000', lambda: wgrad_group_check(1000, ((72, 264), (728, 728), (256, 64)))))
     out.append(('wgrad_group_one_M4099', lambda: wgrad_group_check(4099, ((2912, 728),))))
     out.append(('wgrad_group_production', wgrad_group_production))
+    return out
+
+
+_base8_all_checks = all_checks
+
+
+def all_checks():  # noqa: F811
+    out = _base8_all_checks()
+    for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+        out.append(('attn_spatial_padded_rows_P197_%s' % tag, lambda dt=dt: attn_spatial(dt, 3, 197, 8, 64, pad=True)))
+        out.append(('attn_spatial_padded_rows_P362_%s' % tag, lambda dt=dt: attn_spatial(dt, 2, 362, 8, 64, pad=True)))
+        out.append(('attn_spatial_padded_rows_P50_h2_d32_%s' % tag, lambda dt=dt: attn_spatial(dt, 3, 50, 2, 32, pad=True)))
+        out.append(('attn_temporal_padded_rows_F9_%s' % tag, lambda dt=dt: attn_temporal(dt, 2, 9, 37, 8, 64, pad=True)))
+        out.append(('attn_temporal_padded_rows_F17_%s' % tag, lambda dt=dt: attn_temporal(dt, 2, 17, 19, 8, 64, pad=True)))
+        out.append(('attn_temporal_padded_rows_F5_h2_d32_%s' % tag, lambda dt=dt: attn_temporal(dt, 3, 5, 11, 2, 32, pad=True)))
     return out
