@@ -61,6 +61,8 @@ def parse():
                     help='opt-in: skip the rows of the last layer that cannot reach the logits (identical results; '
                          'STTransformer.dead_row_elimination).  Without the flag the default run still reports this '
                          'variant\'s step time as an extra field')
+    ap.add_argument('--no-dre-extra', action='store_true',
+                    help='skip the extra K steps that fill the with_dead_row_elimination field (profiled runs: one kind of step in the trace)')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
     return ap.parse_args()
@@ -212,7 +214,7 @@ def main():
 
     # ---- extra field: the same K steps with the opt-in dead-row elimination (identical logits / gradients, fewer FLOPs)
     dre = None
-    if not a.eval and not a.dead_row_elimination and a.depth > 1:
+    if not a.eval and not a.dead_row_elimination and not a.no_dre_extra and a.depth > 1:
         model.set_dead_row_elimination(True)
         step(); step()
         sync()
