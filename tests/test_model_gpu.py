@@ -18,6 +18,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import recipe  # noqa: E402
 
@@ -717,3 +718,26 @@ def test_grouped_weight_gradients_match_ungrouped():
         for a, b in zip(results[key], results[base]):
             assert float(b.norm()) > 0
             assert relerr(a, b) < 1e-5, key
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_path_rehearsal():
+    """bench.py's N > 1 path (process group, parameter broadcast, flat bucket with the early all-reduce, deferred 1/W in
+    the fused optimizer, barrier + max-over-ranks timing, per-rank diagnostics) launched the way the driver launches it,
+    with two ranks on this one GPU and gloo instead of RCCL (ISTVT_BENCH_REHEARSAL): functional only."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ISTVT_BENCH_REHEARSAL='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+           '--frames', '4', '--size', '96', '--depth', '2', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['distributed']['ranks'] == 2 and len(out['distributed']['per_rank_ms_per_step']) == 2
+    assert out['value'] > 0 and abs(out['value'] - 2 * 2 * 1e3 / out['ms_per_step']) < 1e-2 * out['value']
+    assert 'roofline' in out and out['vs_baseline'] is None
