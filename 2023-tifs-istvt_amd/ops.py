@@ -605,9 +605,10 @@ def tokens_fwd(feats: Tensor, space: Tensor, temporal: Tensor, pos: Tensor, pad:
     if pos.shape[2] < P:
         raise RuntimeError('pos_embedding has %d tokens per frame, input needs %d' % (pos.shape[2], P))
     x = empty_rows(B * F * P, D, feats.dtype, feats.device, pad)
-    _lib.check(_lib.lib().istvt_tokens_fwd(feats.data_ptr(), space.data_ptr(), temporal.data_ptr(), pos.data_ptr(),
-                                           x.data_ptr(), x.stride(0), B, F, P, D, pos.shape[2], dtype_code(feats),
-                                           _stream()), 'istvt_tokens_fwd')
+    with prof('tokens_fwd', (B * T * hw + B * F * P) * D * feats.element_size()):
+        _lib.check(_lib.lib().istvt_tokens_fwd(feats.data_ptr(), space.data_ptr(), temporal.data_ptr(), pos.data_ptr(),
+                                               x.data_ptr(), x.stride(0), B, F, P, D, pos.shape[2], dtype_code(feats),
+                                               _stream()), 'istvt_tokens_fwd')
     return x.view(B, F * P, D)
 
 
@@ -616,9 +617,10 @@ def tokens_bwd(dx: Tensor, B: int, T: int, hw: int, D: int, dspace: Tensor, dtem
     dx, lddx = rows(_req(dx))
     F, P = T + 1, hw + 1
     dfeats = torch.empty((B, T, hw, D), dtype=dx.dtype, device=dx.device) if need_dfeats else None
-    _lib.check(_lib.lib().istvt_tokens_bwd(dx.data_ptr(), lddx, _ptr(dfeats), dspace.data_ptr(), dtemporal.data_ptr(),
-                                           dpos.data_ptr(), B, F, P, D, dpos.shape[2], dtype_code(dx), _stream()),
-               'istvt_tokens_bwd')
+    with prof('tokens_bwd', (B * F * P + (B * T * hw if need_dfeats else 0)) * D * dx.element_size()):
+        _lib.check(_lib.lib().istvt_tokens_bwd(dx.data_ptr(), lddx, _ptr(dfeats), dspace.data_ptr(), dtemporal.data_ptr(),
+                                               dpos.data_ptr(), B, F, P, D, dpos.shape[2], dtype_code(dx), _stream()),
+                   'istvt_tokens_bwd')
     return dfeats
 
 

@@ -75,8 +75,9 @@ def bn_forward_stats(u: Tensor, M: int, C: int, gamma: Tensor, beta: Tensor, rme
     if training:
         if acc is None:
             acc = new_stats(C, u.device)
-            _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0, 0].data_ptr(), acc[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
-                       'istvt_bn_stats')
+            with ops.prof('bn_stats', M * C * u.element_size()):
+                _lib.check(L.istvt_bn_stats(u.data_ptr(), acc[0, 0].data_ptr(), acc[0, 1].data_ptr(), M, C, dtype_code(u),
+                                            _stream()), 'istvt_bn_stats')
         reduce_stats(acc, C)
         s0, s1 = acc[0, 0].data_ptr(), acc[0, 1].data_ptr()
     else:
@@ -117,18 +118,20 @@ def bn_backward(dz: Tensor, u: Tensor, st: BNState, gamma: Tensor, M: int, C: in
     L = _lib.lib()
     if stats is None:
         stats = new_stats(C, u.device)
-        _lib.check(L.istvt_bn_bwd_stats(dz.data_ptr(), u.data_ptr(), st.ptr(),
-                                        stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
-                   'istvt_bn_bwd_stats')
+        with ops.prof('bn_bwd_stats', 2 * M * C * u.element_size()):
+            _lib.check(L.istvt_bn_bwd_stats(dz.data_ptr(), u.data_ptr(), st.ptr(),
+                                            stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), M, C, dtype_code(u), _stream()),
+                       'istvt_bn_bwd_stats')
     reduce_stats(stats, C)
     du = torch.empty_like(u)
     if dg is None:
         dg = torch.zeros((C,), dtype=torch.float32, device=u.device)
     if db is None:
         db = torch.zeros((C,), dtype=torch.float32, device=u.device)
-    _lib.check(L.istvt_bn_bwd_apply(dz.data_ptr(), u.data_ptr(), st.ptr(), gamma.data_ptr(),
-                                    stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), du.data_ptr(), dg.data_ptr(),
-                                    db.data_ptr(), M, C, int(training), dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
+    with ops.prof('bn_bwd_apply', 3 * M * C * u.element_size()):
+        _lib.check(L.istvt_bn_bwd_apply(dz.data_ptr(), u.data_ptr(), st.ptr(), gamma.data_ptr(),
+                                        stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), du.data_ptr(), dg.data_ptr(),
+                                        db.data_ptr(), M, C, int(training), dtype_code(u), _stream()), 'istvt_bn_bwd_apply')
     return du, dg, db
 
 
@@ -156,9 +159,10 @@ def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn
                  out: Optional[Tensor] = None) -> Tensor:
     """out: float32 [C][9] buffer to accumulate into (a depthwise weight's .grad viewed (C, 9))."""
     dw = out if out is not None else torch.zeros((C, 9), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().istvt_dwconv3x3_wgrad(x.data_ptr(), in_bn.ptr() if in_bn else None, int(in_relu), dout.data_ptr(),
-                                                dw.data_ptr(), Fr, H, W, C, dtype_code(x), _stream()),
-               'istvt_dwconv3x3_wgrad')
+    with ops.prof('dwconv3x3_wgrad', 2 * Fr * H * W * C * x.element_size()):
+        _lib.check(_lib.lib().istvt_dwconv3x3_wgrad(x.data_ptr(), in_bn.ptr() if in_bn else None, int(in_relu),
+                                                    dout.data_ptr(), dw.data_ptr(), Fr, H, W, C, dtype_code(x), _stream()),
+                   'istvt_dwconv3x3_wgrad')
     return dw
 
 
@@ -286,8 +290,10 @@ class StemFn(Function):
             uS, bnS = pw_bn(name + '.skipbn', xs, wsk, Ms, cout)
             out = torch.empty((Ms, cout), dtype=dtype, device=dev)
             amax = torch.empty((Ms, cout), dtype=torch.uint8, device=dev)
-            _lib.check(L.istvt_pool_add_fwd(uB.data_ptr(), bnB.ptr(), uS.data_ptr(), bnS.ptr(), out.data_ptr(),
-                                            amax.data_ptr(), Fr, H, H, cout, ops._DT[dtype], _stream()), 'istvt_pool_add_fwd')
+            esz = uB.element_size()          # reads the full-resolution map and the skip, writes the pooled map + argmax bytes
+            with ops.prof('pool_add_fwd', M * cout * esz + Ms * cout * (2 * esz + 1)):
+                _lib.check(L.istvt_pool_add_fwd(uB.data_ptr(), bnB.ptr(), uS.data_ptr(), bnS.ptr(), out.data_ptr(),
+                                                amax.data_ptr(), Fr, H, H, cout, ops._DT[dtype], _stream()), 'istvt_pool_add_fwd')
             blocks.append(dict(name=name, i0=i0, cin=cin_, cout=cout, pre_relu=pre_relu, H=H, Hs=Hs, X=X, d1=d1, uA=uA,
                                bnA=bnA, d2=d2, uB=uB, bnB=bnB, xs=xs, uS=uS, bnS=bnS, amax=amax, wdwA=wdwA, wpwA=wpwA,
                                wdwB=wdwB, wpwB=wpwB, wsk=wsk))
@@ -352,8 +358,9 @@ class StemFn(Function):
             dxs = ops.linear_dgrad(duS, blk['wsk'])
             # rep path: maxpool -> BN_B -> pointwise_B -> depthwise_B -> ReLU -> BN_A -> pointwise_A -> depthwise_A
             dzB = torch.empty((M, cout), dtype=dtype, device=dev)
-            _lib.check(L.istvt_pool_bwd(dOut.data_ptr(), blk['amax'].data_ptr(), dzB.data_ptr(), Fr, H, H, cout, dtc,
-                                        _stream()), 'istvt_pool_bwd')
+            with ops.prof('pool_bwd', (M + Ms) * cout * dzB.element_size() + Ms * cout):
+                _lib.check(L.istvt_pool_bwd(dOut.data_ptr(), blk['amax'].data_ptr(), dzB.data_ptr(), Fr, H, H, cout, dtc,
+                                            _stream()), 'istvt_pool_bwd')
             nB = '%s.rep.%d' % (name, i0 + 4)
             duB = bn_bwd(dzB, blk['uB'], blk['bnB'], nB, M, cout)
             del dzB
