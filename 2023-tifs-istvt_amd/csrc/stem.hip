@@ -864,30 +864,41 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
         const long m = i / vpr;
         const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
         const long f = m / ((long)Wo * Ho);
+        // All nine taps (clamped addresses) and the skip row are requested before any is used: with each load inside its
+        // bounds test the taps were nine dependent global-memory latencies per output (2.2 TB/s of algorithmic traffic).
+        typename Mma<T>::frag raw[9];
+        bool ok[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = 2 * yo - 1 + dy;
+            const int yc = min(max(y, 0), H - 1);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * xo - 1 + dx;
+                const int xc = min(max(xx, 0), W - 1);
+                ok[dy * 3 + dx] = y >= 0 && y < H && xx >= 0 && xx < W;
+                raw[dy * 3 + dx] = frag_load(x + ((f * H + yc) * W + xc) * C + ch * 8);
+            }
+        }
+        const typename Mma<T>::frag sraw = frag_load(skip + m * C + ch * 8);
+        float mu[8], sc[8], be[8];
+        load8(bnx + ch * 8, mu); load8(bnx + 2 * C + ch * 8, sc); load8(bnx + 3 * C + ch * 8, be);
         float best[8];
         int bi[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int y = 2 * yo - 1 + dy;
-            if (y < 0 || y >= H) continue;
+        for (int t = 0; t < 9; ++t) {
+            if (!ok[t]) continue;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int xx = 2 * xo - 1 + dx;
-                if (xx < 0 || xx >= W) continue;
-                float v[8];
-                load8(x + ((f * H + y) * W + xx) * C + ch * 8, v);
-                bn_affine8(v, bnx, C, ch * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float z = to_f32(from_f32<T>(v[j]));                   // the value a separate BN pass would store
-                    if (z > best[j]) { best[j] = z; bi[j] = dy * 3 + dx; }       // first maximum wins (torch)
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float z = to_f32(from_f32<T>((Mma<T>::get(raw[t], j) - mu[j]) * sc[j] + be[j]));   // the value a separate BN pass would store
+                if (z > best[j]) { best[j] = z; bi[j] = t; }                                  // first maximum wins (torch)
             }
         }
         float sv[8];
-        load8(skip + m * C + ch * 8, sv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = Mma<T>::get(sraw, j);
         bn_affine8(sv, bns, C, ch * 8);
         uint64_t packed = 0;
 #pragma unroll
@@ -914,24 +925,34 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
         const long f = m / ((long)W * H);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int yo0 = y >> 1, xo0 = x >> 1;          // window yo covers rows 2yo-1 .. 2yo+1
+        // the (<= 4) windows' gradient rows and argmax bytes are all requested first (clamped addresses), then used
+        typename Mma<T>::frag draw[4];
+        uint64_t pk[4];
+        int want[4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int yo = yo0 + a;
             const int dy = y - (2 * yo - 1);
-            if (yo >= Ho || dy < 0 || dy > 2) continue;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int xo = xo0 + b;
                 const int dx = x - (2 * xo - 1);
-                if (xo >= Wo || dx < 0 || dx > 2) continue;
-                const long mo = (f * Ho + yo) * Wo + xo;
-                const uint64_t packed = *reinterpret_cast<const uint64_t*>(argmax + mo * C + ch * 8);
-                float d[8];
-                load8(dout + mo * C + ch * 8, d);
-                const int want = dy * 3 + dx;
+                const bool okw = yo < Ho && dy >= 0 && dy <= 2 && xo < Wo && dx >= 0 && dx <= 2;
+                const long mo = (f * Ho + min(yo, Ho - 1)) * Wo + min(xo, Wo - 1);
+                pk[a * 2 + b] = *reinterpret_cast<const uint64_t*>(argmax + mo * C + ch * 8);
+                draw[a * 2 + b] = frag_load(dout + mo * C + ch * 8);
+                want[a * 2 + b] = okw ? dy * 3 + dx : 255;          // 255 never matches an argmax code (0..8)
+            }
+        }
+        // (this loop is the kernel's time: 32 byte tests per thread at full resolution -- v_bfe_u32 on the two halves
+        //  of the packed argmax word, not 64-bit shifts)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if ((int)((packed >> (8 * j)) & 0xff) == want) acc[j] += d[j];
+        for (int w = 0; w < 4; ++w) {
+            const unsigned lo = (unsigned)pk[w], hi = (unsigned)(pk[w] >> 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned code = __builtin_amdgcn_ubfe(j < 4 ? lo : hi, 8 * (j & 3), 8);
+                acc[j] += code == (unsigned)want[w] ? Mma<T>::get(draw[w], j) : 0.f;
             }
         }
         store8(dz + m * C + ch * 8, acc);
