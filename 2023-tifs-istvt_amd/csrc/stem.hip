@@ -912,50 +912,62 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
 }
 
 // dz[f,y,x,c] = sum over the (<= 4) windows containing (y,x) of dout[window] * [argmax(window) == (y,x)]
+// One thread = one 8-channel chunk of a 2x2 pixel quad {2a-1, 2a} x {2b-1, 2b}: the quad's pixels lie in the windows
+// (a-1|a, b-1|b) only, so four window loads (gradient row + argmax bytes) serve four outputs.  One thread per PIXEL
+// read its <= 4 windows itself: 96 bytes loaded per 16 written, and the kernel ran at the rate of the load path
+// (2.3 TB/s of algorithmic traffic) although its HBM traffic was the algorithmic 645 MB per launch.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
-                                                       T* __restrict__ dz, long Mi, int H, int W, int C, int Ho,
+                                                       T* __restrict__ dz, long nquads, int H, int W, int C, int Ho,
                                                        int Wo) {
     const int vpr = C / 8;
-    const long nitems = Mi * vpr, stride = (long)gridDim.x * 256;
-    for (long i = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < nitems; i += stride) {   // windows of neighbouring rows overlap: keep them in one XCD's L2
+    const int QH = H / 2 + 1, QW = W / 2 + 1;
+    const long nitems = nquads * vpr, stride = (long)gridDim.x * 256;
+    for (long i = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < nitems; i += stride) {
         const int ch = (int)(i % vpr);
-        const long m = i / vpr;
-        const int x = (int)(m % W), y = (int)((m / W) % H);
-        const long f = m / ((long)W * H);
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int yo0 = y >> 1, xo0 = x >> 1;          // window yo covers rows 2yo-1 .. 2yo+1
-        // the (<= 4) windows' gradient rows and argmax bytes are all requested first (clamped addresses), then used
+        const long q = i / vpr;
+        const int b = (int)(q % QW), a = (int)((q / QW) % QH);
+        const long f = q / ((long)QW * QH);
+        // windows (a-1+wa, b-1+wb), wa, wb in {0, 1}
         typename Mma<T>::frag draw[4];
-        uint64_t pk[4];
-        int want[4];
+        unsigned lo[4], hi[4];
+        bool okw[4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int yo = yo0 + a;
-            const int dy = y - (2 * yo - 1);
+        for (int wa = 0; wa < 2; ++wa)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int xo = xo0 + b;
-                const int dx = x - (2 * xo - 1);
-                const bool okw = yo < Ho && dy >= 0 && dy <= 2 && xo < Wo && dx >= 0 && dx <= 2;
-                const long mo = (f * Ho + min(yo, Ho - 1)) * Wo + min(xo, Wo - 1);
-                pk[a * 2 + b] = *reinterpret_cast<const uint64_t*>(argmax + mo * C + ch * 8);
-                draw[a * 2 + b] = frag_load(dout + mo * C + ch * 8);
-                want[a * 2 + b] = okw ? dy * 3 + dx : 255;          // 255 never matches an argmax code (0..8)
+            for (int wb = 0; wb < 2; ++wb) {
+                const int yo = a - 1 + wa, xo = b - 1 + wb;
+                okw[wa * 2 + wb] = yo >= 0 && yo < Ho && xo >= 0 && xo < Wo;
+                const long mo = (f * Ho + min(max(yo, 0), Ho - 1)) * Wo + min(max(xo, 0), Wo - 1);
+                const uint64_t pk = *reinterpret_cast<const uint64_t*>(argmax + mo * C + ch * 8);
+                lo[wa * 2 + wb] = (unsigned)pk; hi[wa * 2 + wb] = (unsigned)(pk >> 32);
+                draw[wa * 2 + wb] = frag_load(dout + mo * C + ch * 8);
+            }
+        // pixel (2a-1+pa, 2b-1+pb): position (dy, dx) = (2 - 2 wa + pa ... ) inside window (wa, wb): dy = (2a-1+pa) - (2(a-1+wa)-1)
+        //   = 2 - 2 wa + pa, valid when 0 <= dy <= 2, i.e. (pa, wa) in {(0,0): 2, (0,1): 0, (1,1): 1}; the same for dx
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+            const int y = 2 * a - 1 + pa;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int x = 2 * b - 1 + pb;
+                if (y < 0 || y >= H || x < 0 || x >= W) continue;
+                float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int wa = pa; wa < 2; ++wa)              // pa = 1 (even row) lies in window row a only
+#pragma unroll
+                    for (int wb = pb; wb < 2; ++wb) {
+                        const int w = wa * 2 + wb;
+                        const unsigned want = okw[w] ? (unsigned)((2 - 2 * wa + pa) * 3 + (2 - 2 * wb + pb)) : 255u;   // 255 never matches (codes 0..8)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned code = __builtin_amdgcn_ubfe(j < 4 ? lo[w] : hi[w], 8 * (j & 3), 8);
+                            acc[j] += code == want ? Mma<T>::get(draw[w], j) : 0.f;
+                        }
+                    }
+                store8(dz + ((f * H + y) * W + x) * C + ch * 8, acc);
             }
         }
-        // (this loop is the kernel's time: 32 byte tests per thread at full resolution -- v_bfe_u32 on the two halves
-        //  of the packed argmax word, not 64-bit shifts)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned lo = (unsigned)pk[w], hi = (unsigned)(pk[w] >> 32);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned code = __builtin_amdgcn_ubfe(j < 4 ? lo : hi, 8 * (j & 3), 8);
-                acc[j] += code == (unsigned)want[w] ? Mma<T>::get(draw[w], j) : 0.f;
-            }
-        }
-        store8(dz + m * C + ch * 8, acc);
     }
 }
 
@@ -991,9 +1003,9 @@ extern "C" int istvt_pool_bwd(const void* dout, const uint8_t* argmax, void* dz,
                               int dtype, hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long Mi = (long)Fr * H * W;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(ew_grid(Mi * (C / 8))), dim3(256), 0, stream,
-                                             (const T*)dout, argmax, (T*)dz, Mi, H, W, C, Ho, Wo));
+    const long nquads = (long)Fr * (H / 2 + 1) * (W / 2 + 1);      // 2x2 pixel quads, see the kernel
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(ew_grid(nquads * (C / 8))), dim3(256), 0, stream,
+                                             (const T*)dout, argmax, (T*)dz, nquads, H, W, C, Ho, Wo));
     return istvt_check_launch();
 }
 
