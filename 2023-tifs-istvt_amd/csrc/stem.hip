@@ -207,25 +207,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const double* s2, T* __restrict__ du, float* dgamma,
                                                            float* dbeta, long M, int C, int batch_stats) {
     const int vpr = C / 8;
-    const long nvec = M * vpr, stride = (long)gridDim.x * 256;
+    const long nvec = M * vpr;
     // eval mode (running statistics are constants): du = gamma * rstd * dz, no mean / projection terms
     const float invM = batch_stats ? 1.0f / (float)M : 0.0f;
     const float* mean = bnp;
     const float* rstd = bnp + C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
-        const int c0 = (int)(i % vpr) * 8;
-        float d[8], uv[8], mu[8], rs[8], g[8];
-        load8(dz + i * 8, d);
-        load8(u + i * 8, uv);
+    // A thread keeps ONE channel chunk for all its vectors (the stride is a multiple of the chunks per row), so the
+    // per-channel constants are loaded once: read per vector they were 224 bytes of L1 traffic beside 32 bytes of
+    // payload, and the kernel ran at the rate of the load path (3.7 TB/s), not of HBM.
+    const long nthr = ((long)gridDim.x * 256) / vpr * vpr;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t < nthr) {
+        const int c0 = (int)(t % vpr) * 8;
+        float mu[8], rs[8], g[8], k1[8], k2[8];
         load8(mean + c0, mu);
         load8(rstd + c0, rs);
         load8(gamma + c0, g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (uv[j] - mu[j]) * rs[j];
-            d[j] = g[j] * rs[j] * (d[j] - (float)s1[c0 + j] * invM - xh * (float)s2[c0 + j] * invM);
+        for (int j = 0; j < 8; ++j) { k1[j] = (float)s1[c0 + j] * invM; k2[j] = (float)s2[c0 + j] * invM; }
+        long i = t;
+        for (; i + nthr < nvec; i += 2 * nthr) {                 // two vectors in flight
+            float d0[8], u0[8], d1[8], u1[8];
+            load8(dz + i * 8, d0);
+            load8(u + i * 8, u0);
+            load8(dz + (i + nthr) * 8, d1);
+            load8(u + (i + nthr) * 8, u1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x0 = (u0[j] - mu[j]) * rs[j], x1 = (u1[j] - mu[j]) * rs[j];
+                d0[j] = g[j] * rs[j] * (d0[j] - k1[j] - x0 * k2[j]);
+                d1[j] = g[j] * rs[j] * (d1[j] - k1[j] - x1 * k2[j]);
+            }
+            store8(du + i * 8, d0);
+            store8(du + (i + nthr) * 8, d1);
         }
-        store8(du + i * 8, d);
+        if (i < nvec) {
+            float d0[8], u0[8];
+            load8(dz + i * 8, d0);
+            load8(u + i * 8, u0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x0 = (u0[j] - mu[j]) * rs[j];
+                d0[j] = g[j] * rs[j] * (d0[j] - k1[j] - x0 * k2[j]);
+            }
+            store8(du + i * 8, d0);
+        }
     }
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -310,7 +336,11 @@ extern "C" int istvt_bn_bwd_apply(const void* dz, const void* u, const float* bn
                                   const float* gamma, const double* s1, const double* s2, void* du, float* dgamma,
                                   float* dbeta, long M, int C, int batch_stats, int dtype, hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_grid(M * (C / 8))), dim3(256), 0,
+    // few vectors per thread would load the per-channel constants as often as before: a grid of resident size
+    static const long bnb_cap = getenv("ISTVT_BNB_BLOCKS") ? atol(getenv("ISTVT_BNB_BLOCKS")) : 2048;   // sweep 1024 .. 16384: 2.04 .. 2.19 ms per step (flat); 65536: 2.56
+    long bnb = (M * (C / 8) + 255) / 256;
+    if (bnb > bnb_cap) bnb = bnb_cap;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3((unsigned)bnb), dim3(256), 0,
                                              stream, (const T*)dz, (const T*)u, bnp, gamma, s1, s2, (T*)du,
                                              dgamma, dbeta, M, C, batch_stats));
     return istvt_check_launch();
@@ -554,6 +584,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
     __shared__ float sred[2][4][DW_CC];   // [s1|s2][wave][channel]
     __shared__ __attribute__((aligned(16))) float wsm[9][DW_CC];
+    __shared__ __attribute__((aligned(16))) float bnsm[EPI ? 4 : 1][DW_CC];   // the mask source's BatchNorm pack (mean, rstd, scale, beta)
     const int tid = threadIdx.x;
     const int tiles_x = (p.W + DW_TW - 1) / DW_TW, tiles_y = (p.H + DW_TH - 1) / DW_TH;
     // 1-D grid, channel chunk fastest: the workgroups that share a pixel's 128-byte lines (its other
@@ -606,6 +637,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         if (c0 + wc < p.C) load8(p.w + (long)src_tap * p.C + c0 + wc, w8);
         store8(&wsm[tap][wc], w8);
     }
+    if constexpr (EPI) {
+        // per-channel constants of the epilogue, staged like the weights: read from global memory per item they were
+        // 160 bytes of L1 traffic per item beside 48 bytes of payload (mask source, skip gradient, store)
+        if (p.m_bn && tid >= 128 && tid < 128 + 4 * DW_NCH) {
+            const int row = (tid - 128) / DW_NCH, wc = ((tid - 128) % DW_NCH) * 8;
+            float b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c0 + wc < p.C) load8(p.m_bn + (long)row * p.C + c0 + wc, b8);
+            store8(&bnsm[row][wc], b8);
+        }
+    }
     __syncthreads();
 #ifdef ISTVT_DW_DIAG
     tstamp[2] = __builtin_amdgcn_s_memtime();
@@ -646,7 +687,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = mv[j];
-            if (p.m_bn) bn_affine8(z, p.m_bn, p.C, c);
+            if (p.m_bn) {
+                float mu[8], sc[8], be[8];
+                load8(&bnsm[0][wo], mu); load8(&bnsm[2][wo], sc); load8(&bnsm[3][wo], be);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (z[j] - mu[j]) * sc[j] + be[j];
+            }
         }
         if (p.mask_pre) {
 #pragma unroll
@@ -671,8 +717,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         if (p.st_s1 && have_m) {
             // statistics of the (rounded) value that is stored, so they match a separate pass
             float mu[8], rs[8];
-            load8(p.m_bn + c, mu);
-            load8(p.m_bn + p.C + c, rs);
+            load8(&bnsm[0][wo], mu);
+            load8(&bnsm[1][wo], rs);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = to_f32(from_f32<T>(acc[j]));
