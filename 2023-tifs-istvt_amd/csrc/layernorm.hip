@@ -63,9 +63,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     float gm[LN_MAXCH][8], bt[LN_MAXCH][8];
     ln_row_load<float>(gamma, D, lane, gm);
     ln_row_load<float>(beta, D, lane, bt);
+    // the next row of this wavefront is requested before the current one is reduced: one row per (memory latency +
+    // two wave reductions) per wavefront otherwise
+    typename Mma<T>::frag nxt[LN_MAXCH];
+    auto fetch = [&](long m) {
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+            if (e < D) nxt[c] = frag_load(x + m * ldx + e);
+        }
+    };
+    if (wave < M) fetch(wave);
     for (long m = wave; m < M; m += nwaves) {
         float v[LN_MAXCH][8];
-        ln_row_load<T>(x + m * ldx, D, lane, v);
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = e < D ? Mma<T>::get(nxt[c], i) : 0.f;
+        }
+        if (m + nwaves < M) fetch(m + nwaves);
         float mean, rstd;
         ln_stats(v, D, lane, eps, mean, rstd);
 #pragma unroll
@@ -96,13 +113,31 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
     ln_row_load<float>(gamma, D, lane, gm);
     ln_row_load<float>(beta, D, lane, bt);
     const long npos = (long)Bn * P;
+    // the next row of the walk (next frame, or frame 0 of this wavefront's next position) is requested before the
+    // current one is reduced (see ln_fwd_kernel)
+    typename Mma<T>::frag nxt[LN_MAXCH];
+    auto fetch = [&](long m) {
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+            if (e < D) nxt[c] = frag_load(x + m * ldx + e);
+        }
+    };
+    if (wave < npos) fetch(((wave / P) * F) * P + wave % P);
     for (long w = wave; w < npos; w += nwaves) {
         const long b = w / P, pp = w % P;
         float prev[LN_MAXCH][8];
         for (int f = 0; f < F; ++f) {
             const long m = (b * F + f) * P + pp;
             float v[LN_MAXCH][8];
-            ln_row_load<T>(x + m * ldx, D, lane, v);
+#pragma unroll
+            for (int c = 0; c < LN_MAXCH; ++c) {
+                const int e = (lane + 64 * c) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[c][i] = e < D ? Mma<T>::get(nxt[c], i) : 0.f;
+            }
+            if (f + 1 < F) fetch(m + P);
+            else if (w + nwaves < npos) fetch((((w + nwaves) / P) * F) * P + (w + nwaves) % P);
             float mean, rstd;
             ln_stats(v, D, lane, eps, mean, rstd);
 #pragma unroll
