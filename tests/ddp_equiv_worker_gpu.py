@@ -7,6 +7,9 @@ on cuda:0): SURVEY 8(e)'s equivalence test on the REAL model.
      the concatenated batch, up to float32 reduction order -- the exact W == 1 test bed.
   C. the fused SGD step with the 1 / W folded in (GradBucket.defer_scale) gives the parameters of the single-process
      step on the concatenated batch.
+  D. bfloat16, the configuration bench.py runs: transformer slice of the bucket all-reduced early (from the token-assembly
+     backward) with the layer's weight gradients queued and launched as one grid on the side stream == the same ranks
+     with everything on one stream, one weight gradient per launch, one blocking all-reduce after backward.
 """
 import os
 import sys
@@ -27,9 +30,9 @@ from istvt_amd import stem as stem_mod  # noqa: E402
 T, SIDE, DEPTH, PER = 4, 96, 2, 2
 
 
-def build(state=None):
+def build(state=None, dtype=torch.float32):
     torch.manual_seed(0)
-    m = XceptionVidTr(num_frames=T, grid=stem_mod.out_side(SIDE), depth=DEPTH).cuda().train()
+    m = XceptionVidTr(num_frames=T, grid=stem_mod.out_side(SIDE), depth=DEPTH, compute_dtype=dtype).cuda().train()
     if state is not None:
         m.load_state_dict(state)
     return m
@@ -103,10 +106,32 @@ def main():
         errs['C'] = rel(b3.flat_params, b4.flat_params)
         errs['C_moved'] = rel(b3.flat_params, torch.cat([p.detach().flatten() for _, p in parallel.live_named_parameters(build(state0))]))
 
+    # ---- D: bf16, early all-reduce + grouped side-stream weight gradients vs the plain order
+    from istvt_amd import functional as Fn
+    res = []
+    for fancy in (True, False):
+        Fn.set_wgrad_overlap(fancy)
+        Fn.set_wgrad_group(8 if fancy else 1)
+        m5 = build(state0, torch.bfloat16)
+        named = parallel.live_named_parameters(m5)
+        b5 = parallel.GradBucket([p for _, p in named], fuse_accumulate=True)
+        if fancy:
+            b5.enable_early_all_reduce(next(i for i, (n, _) in enumerate(named) if n.startswith('vit.')))
+        for it in range(2):                     # twice: the second step runs with recycled allocator blocks
+            b5.zero()
+            torch.nn.functional.binary_cross_entropy_with_logits(m5(x * (1.0 + 0.5 * it)).view(-1), y).backward()
+            b5.all_reduce()
+        res.append(b5.flat.clone())
+        b5.disable_early_all_reduce()
+    Fn.set_wgrad_overlap(True)
+    Fn.set_wgrad_group(8)
+    errs['D'] = rel(res[0], res[1])
+
     ok = True
     if rank == 0:
         print('data-parallel equivalence (W=%d): %s' % (world, errs), flush=True)
         ok = errs['A'] < 1e-5 and errs['B'] < 2e-5 and errs['C'] < 1e-6 and errs['C_moved'] > 1e-6
+    ok = ok and errs['D'] < 1e-5 and float(res[1].norm()) > 0
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
