@@ -98,6 +98,20 @@ def cpu_baseline(frames, size, depth, clips=2, reps=3):
                                                                  dt, ', '.join('%.1f' % t for t in times))}
 
 
+def config_name(a, world):
+    """BASELINE.json's name for the configuration being run (C2 is the headline one)"""
+    key = (a.batch, a.frames, a.size, a.depth, a.dtype, bool(a.attn_fp8))
+    if key == (32, 8, 224, 12, 'bf16', False):
+        return 'C3' if world == 8 else 'C2'
+    if key == (32, 16, 224, 12, 'bf16', False):
+        return 'C4'
+    if key == (64, 8, 224, 12, 'bf16', True):
+        return 'C5'
+    if key == (1, 4, 96, 2, 'f32', False):
+        return 'C1'
+    return 'custom'
+
+
 def pmc_summary_path():
     """newest committed PMC summary (profiles/pmc/rNN_pmc_whole_step_summary.json)"""
     d = os.path.join(ROOT, 'profiles', 'pmc')
@@ -308,8 +322,9 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if dtype == torch.bfloat16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C2: B=%d/GPU T=%d %dx%d full ISTVT (Xception stem + %d-layer DSTTr) train step '
-                                   '(fwd+bwd+grad all-reduce+SGD), random-init weights' % (a.batch, a.frames, a.size, a.size, a.depth),
+            'config': {'workload': '%s: B=%d/GPU T=%d %dx%d full ISTVT (Xception stem + %d-layer DSTTr) train step '
+                                   '(fwd+bwd+grad all-reduce+SGD), random-init weights'
+                                   % (config_name(a, world), a.batch, a.frames, a.size, a.size, a.depth),
                        'global_batch': world * a.batch, 'frames': a.frames, 'size': a.size, 'depth': a.depth,
                        'parallelism': 'dp%d' % world, 'early_allreduce': bool(world > 1 and not a.no_early_allreduce), 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
         }
