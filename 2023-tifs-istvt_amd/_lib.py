@@ -51,7 +51,7 @@ SIGNATURES = {
     'istvt_dwconv3x3': [P, P, P, I, I, I, I, P, I, I, P, P, I, I, P, I, I, P, P, I, P],
     'istvt_dwconv3x3_wgrad': [P, P, I, P, P, I, I, I, I, I, P],
     'istvt_pool_add_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
-    'istvt_pool_bwd': [P, P, P, I, I, I, I, I, P],
+    'istvt_pool_bwd': [P, P, P, I, I, I, I, P, P, P, P, I, P],
     'istvt_subsample2': [P, P, I, I, I, I, I, P],
     'istvt_splitk_reduce': [P, I, L, P, P],
     'istvt_wgrad_group': [I, P, P, P, P, P, P, P, I, I, P, L, P],

@@ -965,17 +965,32 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ argmax,
                                                        T* __restrict__ dz, long nquads, int H, int W, int C, int Ho,
-                                                       int Wo) {
+                                                       int Wo, const T* __restrict__ u, const float* __restrict__ bnp,
+                                                       double* st_s1, double* st_s2) {
+    // u != null: dz is the output gradient of the BatchNorm whose input was u (the block's last BatchNorm, xception.py:
+    // 75 -> 88): its backward sums  s1 = sum dz,  s2 = sum dz * xhat  are taken here, of the rounded values that are
+    // stored, instead of by a pass over dz and u (istvt_bn_bwd_stats).  A thread keeps one channel chunk for all its
+    // quads (the thread count in use is a multiple of the chunks per pixel): constants and partial sums in registers.
+    extern __shared__ float psum[];                     // [2][C] when u != null
     const int vpr = C / 8;
     const int QH = H / 2 + 1, QW = W / 2 + 1;
-    const long nitems = nquads * vpr, stride = (long)gridDim.x * 256;
-    for (long i = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < nitems; i += stride) {
-        const int ch = (int)(i % vpr);
-        const long q = i / vpr;
+    const long nthr = ((long)gridDim.x * 256) / vpr * vpr;
+    const long t = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const bool stats = u != nullptr;
+    if (stats) {
+        for (int c = threadIdx.x; c < 2 * C; c += 256) psum[c] = 0.f;
+        __syncthreads();
+    }
+    const int ch = (int)(t % vpr);
+    float mu[8], rs[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = 0.f; rs[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; }
+    if (stats && t < nthr) { load8(bnp + ch * 8, mu); load8(bnp + C + ch * 8, rs); }
+    for (long q = t < nthr ? t / vpr : nquads; q < nquads; q += nthr / vpr) {
         const int b = (int)(q % QW), a = (int)((q / QW) % QH);
         const long f = q / ((long)QW * QH);
         // windows (a-1+wa, b-1+wb), wa, wb in {0, 1}
-        typename Mma<T>::frag draw[4];
+        typename Mma<T>::frag draw[4], uraw[4];
         unsigned lo[4], hi[4];
         bool okw[4];
 #pragma unroll
@@ -989,8 +1004,17 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
                 lo[wa * 2 + wb] = (unsigned)pk; hi[wa * 2 + wb] = (unsigned)(pk >> 32);
                 draw[wa * 2 + wb] = frag_load(dout + mo * C + ch * 8);
             }
-        // pixel (2a-1+pa, 2b-1+pb): position (dy, dx) = (2 - 2 wa + pa ... ) inside window (wa, wb): dy = (2a-1+pa) - (2(a-1+wa)-1)
-        //   = 2 - 2 wa + pa, valid when 0 <= dy <= 2, i.e. (pa, wa) in {(0,0): 2, (0,1): 0, (1,1): 1}; the same for dx
+        if (stats) {
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    const int y = min(max(2 * a - 1 + pa, 0), H - 1), x = min(max(2 * b - 1 + pb, 0), W - 1);
+                    uraw[pa * 2 + pb] = frag_load(u + ((f * H + y) * W + x) * C + ch * 8);
+                }
+        }
+        // pixel (2a-1+pa, 2b-1+pb): position dy = 2 - 2 wa + pa inside window row a-1+wa, valid for (pa, wa) in
+        // {(0,0): 2, (0,1): 0, (1,1): 1}; the same for dx
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa) {
             const int y = 2 * a - 1 + pa;
@@ -1012,7 +1036,27 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
                         }
                     }
                 store8(dz + ((f * H + y) * W + x) * C + ch * 8, acc);
+                if (stats) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = to_f32(from_f32<T>(acc[j]));
+                        a1[j] += d;
+                        a2[j] += d * (Mma<T>::get(uraw[pa * 2 + pb], j) - mu[j]) * rs[j];
+                    }
+                }
             }
+        }
+    }
+    if (stats) {
+        if (t < nthr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&psum[ch * 8 + j], a1[j]); atomicAdd(&psum[C + ch * 8 + j], a2[j]); }
+        }
+        __syncthreads();
+        const long rep = (long)(blockIdx.x % STAT_REPLICAS) * 2 * C;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            atomicAdd(st_s1 + rep + c, (double)psum[c]);
+            atomicAdd(st_s2 + rep + c, (double)psum[C + c]);
         }
     }
 }
@@ -1046,12 +1090,20 @@ extern "C" int istvt_pool_add_fwd(const void* x, const float* bnx, const void* s
 }
 
 extern "C" int istvt_pool_bwd(const void* dout, const uint8_t* argmax, void* dz, int Fr, int H, int W, int C,
-                              int dtype, hipStream_t stream) {
+                              const void* u, const float* bnp, double* st_s1, double* st_s2, int dtype,
+                              hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    if (u && (!bnp || !st_s1 || !st_s2 || C > 4096)) return ISTVT_ERR_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long nquads = (long)Fr * (H / 2 + 1) * (W / 2 + 1);      // 2x2 pixel quads, see the kernel
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(ew_grid(nquads * (C / 8))), dim3(256), 0, stream,
-                                             (const T*)dout, argmax, (T*)dz, nquads, H, W, C, Ho, Wo));
+    // with the statistics every workgroup ends in 2 C fp64 atomics: a grid of resident size
+    static const long cap = getenv("ISTVT_POOLB_BLOCKS") ? atol(getenv("ISTVT_POOLB_BLOCKS")) : 2048;
+    long blocks = (nquads * (C / 8) + 255) / 256;
+    if (blocks > cap) blocks = cap;
+    const size_t lds = u ? (size_t)2 * C * sizeof(float) : 0;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, stream,
+                                             (const T*)dout, argmax, (T*)dz, nquads, H, W, C, Ho, Wo, (const T*)u, bnp,
+                                             st_s1, st_s2));
     return istvt_check_launch();
 }
 

@@ -358,11 +358,15 @@ class StemFn(Function):
             dxs = ops.linear_dgrad(duS, blk['wsk'])
             # rep path: maxpool -> BN_B -> pointwise_B -> depthwise_B -> ReLU -> BN_A -> pointwise_A -> depthwise_A
             dzB = torch.empty((M, cout), dtype=dtype, device=dev)
-            with ops.prof('pool_bwd', (M + Ms) * cout * dzB.element_size() + Ms * cout):
-                _lib.check(L.istvt_pool_bwd(dOut.data_ptr(), blk['amax'].data_ptr(), dzB.data_ptr(), Fr, H, H, cout, dtc,
-                                            _stream()), 'istvt_pool_bwd')
+            # the BatchNorm-backward sums of BN_B are taken by the pooling backward as it writes dz (train mode)
+            statsB = new_stats(cout, dev) if training else None
+            with ops.prof('pool_bwd', ((2 if training else 1) * M + Ms) * cout * dzB.element_size() + Ms * cout):
+                _lib.check(L.istvt_pool_bwd(dOut.data_ptr(), blk['amax'].data_ptr(), dzB.data_ptr(), Fr, H, H, cout,
+                                            blk['uB'].data_ptr() if training else None, blk['bnB'].ptr() if training else None,
+                                            statsB[0, 0].data_ptr() if training else None,
+                                            statsB[0, 1].data_ptr() if training else None, dtc, _stream()), 'istvt_pool_bwd')
             nB = '%s.rep.%d' % (name, i0 + 4)
-            duB = bn_bwd(dzB, blk['uB'], blk['bnB'], nB, M, cout)
+            duB = bn_bwd(dzB, blk['uB'], blk['bnB'], nB, M, cout, stats=statsB)
             del dzB
             sB = '%s.rep.%d' % (name, i0 + 3)
             lin_wgrad(sB + '.pointwise.weight', duB, blk['d2'])

@@ -205,11 +205,16 @@ class RepChainFn(Function):
         # ---- rep path, last unit first
         if spec.tail == 'pool':
             dz = torch.empty((M, spec.cout), dtype=dtype, device=dev)
-            _lib.check(L.istvt_pool_bwd(dout.data_ptr(), sv['amax'].data_ptr(), dz.data_ptr(), Fr, H, W, spec.cout, dtc, _stream()),
-                       'istvt_pool_bwd')
+            # train mode: the last unit's BatchNorm-backward sums are taken by the pooling backward as it writes dz
+            last = units[nu - 1]
+            stats = new_stats(spec.cout, dev) if training else None
+            _lib.check(L.istvt_pool_bwd(dout.data_ptr(), sv['amax'].data_ptr(), dz.data_ptr(), Fr, H, W, spec.cout,
+                                        last['u'].data_ptr() if training else None, last['bn'].ptr() if training else None,
+                                        stats[0, 0].data_ptr() if training else None,
+                                        stats[0, 1].data_ptr() if training else None, dtc, _stream()), 'istvt_pool_bwd')
         else:
             dz = dout
-        stats = None
+            stats = None
         dinp = None
         for i in reversed(range(nu)):
             un = units[i]

@@ -207,8 +207,11 @@ int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const
 /* Block tail (xception.py:88,91-100): out = maxpool3x3s2p1(bn_x(x)) + bn_s(skip); argmax: uint8 per output element */
 int istvt_pool_add_fwd(const void* x, const float* bnx, const void* skip, const float* bns, void* out,
                        unsigned char* argmax, int frames, int H, int W, int C, int dtype, istvt_stream_t stream);
+/* u (NULL = off): the input of the block's last BatchNorm (xception.py:75), whose output the pooling consumed; with it
+ * bnp (that BatchNorm's pack) and s1 / s2 (replica-0 rows of a double[R][2][C] accumulator): the kernel adds the
+ * BatchNorm-backward sums  sum dz,  sum dz * xhat  of the values it stores -- no istvt_bn_bwd_stats pass over dz and u */
 int istvt_pool_bwd(const void* dout, const unsigned char* argmax, void* dz, int frames, int H, int W, int C,
-                   int dtype, istvt_stream_t stream);
+                   const void* u, const float* bnp, double* s1, double* s2, int dtype, istvt_stream_t stream);
 /* input of the stride-2 1x1 skip conv (xception.py:57): out[f][y][x] = in[f][2y][2x] */
 int istvt_subsample2(const void* in, void* out, int frames, int H, int W, int C, int dtype, istvt_stream_t stream);
 

@@ -391,8 +391,23 @@ def pool_check(dtype, Fr=2, H=21, W=21, C=24):
     dout = rnd((Fr, C, Ho, Ho), dtype, 7)
     ref.backward(dout.double())
     dz = torch.empty_like(xn)
-    _lib.check(L.istvt_pool_bwd(_nhwc(dout).data_ptr(), am.data_ptr(), dz.data_ptr(), Fr, H, W, C, ops.dtype_code(xn), ops._stream()), 'poolb')
-    return max(relerr(out, _nhwc(ref)), relerr(dz, _nhwc(z.grad))), TOL[dtype]
+    _lib.check(L.istvt_pool_bwd(_nhwc(dout).data_ptr(), am.data_ptr(), dz.data_ptr(), Fr, H, W, C, None, None, None, None,
+                                ops.dtype_code(xn), ops._stream()), 'poolb')
+    e = max(relerr(out, _nhwc(ref)), relerr(dz, _nhwc(z.grad)))
+    # the same with the BatchNorm-backward sums of the pooled BatchNorm taken on the way: dz identical, sums equal to the
+    # standalone statistics pass over (dz, u)
+    b1.mean.copy_(rnd((C,), torch.float32, 8, 0.2)); b1.rstd.copy_(rnd((C,), torch.float32, 9, 0.1) + 1.0)
+    dz2 = torch.empty_like(xn)
+    acc = S.new_stats(C, DEV)
+    _lib.check(L.istvt_pool_bwd(_nhwc(dout).data_ptr(), am.data_ptr(), dz2.data_ptr(), Fr, H, W, C, xn.data_ptr(), b1.ptr(),
+                                acc[0, 0].data_ptr(), acc[0, 1].data_ptr(), ops.dtype_code(xn), ops._stream()), 'poolb stats')
+    S.reduce_stats(acc, C)
+    ref_acc = S.new_stats(C, DEV)
+    _lib.check(L.istvt_bn_bwd_stats(dz.data_ptr(), xn.data_ptr(), b1.ptr(), ref_acc[0, 0].data_ptr(), ref_acc[0, 1].data_ptr(),
+                                    Fr * H * W, C, ops.dtype_code(xn), ops._stream()), 'bn_bwd_stats')
+    S.reduce_stats(ref_acc, C)
+    e = max(e, 0.0 if torch.equal(dz2, dz) else 1.0, relerr(acc[0], ref_acc[0]) * (TOL[dtype] / 2e-5))
+    return e, TOL[dtype]
 
 
 Y_TOL_BF16 = 3.5e-2
