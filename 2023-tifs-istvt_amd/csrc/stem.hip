@@ -971,16 +971,12 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
     // 75 -> 88): its backward sums  s1 = sum dz,  s2 = sum dz * xhat  are taken here, of the rounded values that are
     // stored, instead of by a pass over dz and u (istvt_bn_bwd_stats).  A thread keeps one channel chunk for all its
     // quads (the thread count in use is a multiple of the chunks per pixel): constants and partial sums in registers.
-    extern __shared__ float psum[];                     // [2][C] when u != null
+    __shared__ float part[2][256][8];                   // the threads' partial sums (u != null)
     const int vpr = C / 8;
     const int QH = H / 2 + 1, QW = W / 2 + 1;
     const long nthr = ((long)gridDim.x * 256) / vpr * vpr;
     const long t = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const bool stats = u != nullptr;
-    if (stats) {
-        for (int c = threadIdx.x; c < 2 * C; c += 256) psum[c] = 0.f;
-        __syncthreads();
-    }
     const int ch = (int)(t % vpr);
     float mu[8], rs[8], a1[8], a2[8];
 #pragma unroll
@@ -1048,15 +1044,20 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
         }
     }
     if (stats) {
-        if (t < nthr) {
+        // the threads of this workgroup that hold channel chunk k are tid = k0, k0 + vpr, ...: summed in that fixed order
+        // (fp32 atomics into LDS would make the sums -- and through them every gradient upstream -- depend on timing)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&psum[ch * 8 + j], a1[j]); atomicAdd(&psum[C + ch * 8 + j], a2[j]); }
-        }
+        for (int j = 0; j < 8; ++j) { part[0][threadIdx.x][j] = a1[j]; part[1][threadIdx.x][j] = a2[j]; }
         __syncthreads();
+        const long t0 = t - threadIdx.x;                          // this workgroup's first thread index
         const long rep = (long)(blockIdx.x % STAT_REPLICAS) * 2 * C;
         for (int c = threadIdx.x; c < C; c += 256) {
-            atomicAdd(st_s1 + rep + c, (double)psum[c]);
-            atomicAdd(st_s2 + rep + c, (double)psum[C + c]);
+            const int k = c >> 3, j = c & 7;
+            const int first = (int)(((long)k - t0 % vpr + vpr) % vpr);
+            float s1 = 0.f, s2 = 0.f;
+            for (int tt = first; tt < 256 && t0 + tt < nthr; tt += vpr) { s1 += part[0][tt][j]; s2 += part[1][tt][j]; }
+            atomicAdd(st_s1 + rep + c, (double)s1);
+            atomicAdd(st_s2 + rep + c, (double)s2);
         }
     }
 }
@@ -1093,15 +1094,14 @@ extern "C" int istvt_pool_bwd(const void* dout, const uint8_t* argmax, void* dz,
                               const void* u, const float* bnp, double* st_s1, double* st_s2, int dtype,
                               hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
-    if (u && (!bnp || !st_s1 || !st_s2 || C > 4096)) return ISTVT_ERR_SHAPE;
+    if (u && (!bnp || !st_s1 || !st_s2)) return ISTVT_ERR_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long nquads = (long)Fr * (H / 2 + 1) * (W / 2 + 1);      // 2x2 pixel quads, see the kernel
     // with the statistics every workgroup ends in 2 C fp64 atomics: a grid of resident size
     static const long cap = getenv("ISTVT_POOLB_BLOCKS") ? atol(getenv("ISTVT_POOLB_BLOCKS")) : 2048;
     long blocks = (nquads * (C / 8) + 255) / 256;
     if (blocks > cap) blocks = cap;
-    const size_t lds = u ? (size_t)2 * C * sizeof(float) : 0;
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, stream,
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,
                                              (const T*)dout, argmax, (T*)dz, nquads, H, W, C, Ho, Wo, (const T*)u, bnp,
                                              st_s1, st_s2));
     return istvt_check_launch();
