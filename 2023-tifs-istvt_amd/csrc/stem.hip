@@ -653,24 +653,45 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 #endif
 
     float st1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Taps outside, this thread's items inside: a tap's weights are read from LDS once for the four items (the weights
+    // were two thirds of the kernel's LDS reads: 27 x the output bytes), the accumulators of all items stay live.
+    float accs[DW_ITEMS][8];
+#pragma unroll
+    for (int k = 0; k < DW_ITEMS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accs[k][j] = 0.f;
+    {
+        const int pix0 = tid / DW_NCH;
+        const int py0 = pix0 / DW_TW, px0 = pix0 % DW_TW;
+        constexpr int ROWSTEP = DW_PIXSTEP / DW_TW;         // tile rows between a thread's consecutive items
+        static_assert(DW_PIXSTEP % DW_TW == 0, "a thread's items share their column");
+        const T* tbase = tile + (py0 * DW_LW + px0) * DW_CC + ch * 8;
+        const float* wbase = &wsm[0][ch * 8];
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {                 // a real loop: nothing of tap t + 1 is live during tap t
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            float w8[8];
+            load8(wbase + tap * DW_CC, w8);
+            const T* tp = tbase + (dy * DW_LW + dx) * DW_CC;
+#pragma unroll
+            for (int k = 0; k < DW_ITEMS; ++k) {
+                float v[8];
+                load8(tp + ROWSTEP * k * DW_LW * DW_CC, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accs[k][j] += v[j] * w8[j];
+            }
+        }
+    }
     auto item = [&](const int k) {
         const int pix = tid / DW_NCH + DW_PIXSTEP * k;
         const int py = pix / DW_TW, px = pix % DW_TW;
         const int y = y0 + py, x = x0 + px;
         if (y >= p.H || x >= p.W || c >= p.C) return;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = accs[k][j];
         int wo = ch * 8;
-        asm volatile("" : "+v"(wo));              // opaque per item: the weight reads must not be hoisted into 72 registers
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                float v[8], w8[8];
-                load8(tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8, v);
-                load8(&wsm[dy * 3 + dx][wo], w8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v[j] * w8[j];
-            }
+        asm volatile("" : "+v"(wo));              // opaque per item: the constants must not be hoisted across items
         const long off = ((f * p.H + y) * p.W + x) * p.C + c;
         if constexpr (EPI) {
         // epilogue order: ReLU mask of the rep path (pre) -> add the skip-path gradient at the
@@ -733,7 +754,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
         static_assert(DW_ITEMS == 4, "item(0..3)");
         item(0); item(1); item(2); item(3);
     } else {
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < DW_ITEMS; ++k) item(k);
     }
 #ifdef ISTVT_DW_DIAG
