@@ -17,14 +17,14 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     'istvt_gemm': [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, I, I, I, F, P, P, I, P],
     'istvt_layernorm_fwd': [P, L, P, P, P, L, P, P, L, I, F, I, P],
-    'istvt_layernorm_fwd_diff': [P, L, P, P, P, L, P, L, P, P, I, I, I, I, F, I, P],
-    'istvt_layernorm_bwd': [P, L, P, L, P, L, P, P, P, P, L, P, L, P, P, P, L, I, I, I, I, P],
+    'istvt_layernorm_bwd': [P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, L, L, I, I, P],
+    'istvt_layernorm_bwd_ws_elems': [L, I],
     'istvt_attn_spatial_fwd': [P, L, P, L, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_bwd': [P, L, P, P, L, P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_fwd_fp8': [P, L, P, L, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_bwd_fp8': [P, L, P, P, L, P, P, P, I, I, I, I, F, I, P],
-    'istvt_attn_temporal_fwd': [P, L, P, P, L, I, I, I, I, I, F, I, P],
-    'istvt_attn_temporal_bwd': [P, L, P, P, P, P, L, I, I, I, I, I, F, I, P],
+    'istvt_attn_temporal_fwd': [P, L, P, L, P, L, I, I, I, I, I, F, I, I, P],
+    'istvt_attn_temporal_bwd': [P, L, P, L, P, L, P, P, I, I, I, I, I, F, I, I, P],
     'istvt_tokens_fwd': [P, P, P, P, P, L, I, I, I, I, I, I, P],
     'istvt_tokens_bwd': [P, L, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],

@@ -1,8 +1,12 @@
 // Per-position temporal self-attention over the frame axis (reference:
 // TemporalResidualAttention.forward, network/vivit/module.py:197-205).  For every
 // (clip b, position p, head h):  O = softmax(Q K^T * DH^-1/2) V with Q,K,V of shape [F][DH],
-// F = T+1 <= 17.  The frame differencing of module.py:193 is NOT done here: q,k arrive already
-// projected from the differenced LayerNorm output (see layernorm.hip).
+// F = T+1 <= 17.  diff != 0 (TemporalResidualAttention): the frame differencing of module.py:193 happens HERE, on the
+// projected rows.  to_qk has no bias (module.py:182), so to_qk(x[f] - x[f-1]) = to_qk(x[f]) - to_qk(x[f-1]): the caller
+// projects the un-differenced LayerNorm output ONCE with [to_qk | to_v] stacked (one GEMM, one activation tensor) and
+// the kernels take q'[f] = q[f] - q[f-1], k'[f] = k[f] - k[f-1] for f >= 2 (frames 0, 1 unchanged) in registers -- all
+// F frames of a position are in the wavefront anyway.  The backward kernels return the gradient with respect to the
+// UN-differenced rows (the adjoint: d q[f] = d q'[f] - d q'[f+1] for f + 1 >= 2), so one input-gradient GEMM follows.
 //
 // 0.1 % of the model's FLOPs and F x F tiles far below an MFMA tile: this is a data-movement
 // kernel, bound by HBM.  A cluster of CL lanes owns one (b,p,h); each lane keeps EPL = DH/CL
@@ -36,10 +40,43 @@ __device__ __forceinline__ float dot4(const float (&a)[4], const float (&b)[4]) 
     return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
 }
 
+// q'[f] = q[f] - q[f-1], k'[f] = k[f] - k[f-1] for f >= 2, in place on rows held in registers (top frame first)
+template <int FMAX, int EPL>
+__device__ __forceinline__ void frame_diff_rows(float (&q)[FMAX][EPL], float (&k)[FMAX][EPL], const int F) {
+#pragma unroll
+    for (int f = FMAX - 1; f >= 2; --f) {
+        if (f < F) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { q[f][e] -= q[f - 1][e]; k[f][e] -= k[f - 1][e]; }
+        }
+    }
+}
+template <int FMAX, int EPL>
+__device__ __forceinline__ void frame_diff_rows1(float (&k)[FMAX][EPL], const int F) {
+#pragma unroll
+    for (int f = FMAX - 1; f >= 2; --f) {
+        if (f < F) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) k[f][e] -= k[f - 1][e];
+        }
+    }
+}
+// the adjoint on the key gradients: d k[f] = d k'[f] - d k'[f+1] for f + 1 >= 2 (in place, bottom frame first)
+template <int FMAX, int EPL>
+__device__ __forceinline__ void frame_diff_adjoint_rows(float (&dk)[FMAX][EPL], const int F) {
+#pragma unroll
+    for (int f = 1; f + 1 < FMAX; ++f) {
+        if (f + 1 < F) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dk[f][e] -= dk[f + 1][e];
+        }
+    }
+}
+
 template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         T* __restrict__ out, int B, int F, int P, int heads,
-                                                        float scale, long ldqk, long ldv) {
+                                                        float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int CL = DH / 4, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -64,6 +101,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
             load4(v + m * ldv + col, vv[f]);
         }
     }
+    if (diff) frame_diff_rows<FMAX, 4>(q, k, F);
 #pragma unroll
     for (int i = 0; i < FMAX; ++i) {
         if (i < F) {
@@ -93,7 +131,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const T* __restrict__ qk
             }
             if (valid) {
                 const long m = row0 + (long)i * P;
-                store4(out + m * ldv + col, o);
+                store4(out + m * ldo + col, o);
             }
         }
     }
@@ -119,7 +157,7 @@ template <typename T, int DH, int FMAX>
 __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         const T* __restrict__ dout, T* __restrict__ dqk,
                                                         T* __restrict__ dv, int B, int F, int P, int heads,
-                                                        float scale, long ldqk, long ldv) {
+                                                        float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int CL = DH / 4, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -142,11 +180,13 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
             load4(qk + m * ldqk + col, q[f]);
             load4(qk + m * ldqk + inner + col, k[f]);
             load4(v + m * ldv + col, vv[f]);
-            load4(dout + m * ldv + col, dO[f]);
+            load4(dout + m * ldo + col, dO[f]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { dk[f][e] = 0.f; dvv[f][e] = 0.f; }
         }
     }
+    if (diff) frame_diff_rows<FMAX, 4>(q, k, F);
+    float dq_held[4] = {0.f, 0.f, 0.f, 0.f};         // diff: d q'[i-1], stored once d q'[i] is known
 #pragma unroll
     for (int i = 0; i < FMAX; ++i) {
         if (i < F) {
@@ -187,8 +227,24 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const T* __restrict__ qk
                     }
                 }
             }
-            if (valid) store4(dqk + m * ldqk + col, dq);
+            if (!diff) {
+                if (valid) store4(dqk + m * ldqk + col, dq);
+            } else {
+                if (i >= 1) {
+                    if (i >= 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dq_held[e] -= dq[e];
+                    }
+                    if (valid) store4(dqk + (m - P) * ldqk + col, dq_held);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dq_held[e] = dq[e];
+            }
         }
+    }
+    if (diff) {
+        if (valid) store4(dqk + (row0 + (long)(F - 1) * P) * ldqk + col, dq_held);
+        frame_diff_adjoint_rows<FMAX, 4>(dk, F);
     }
     if (valid) {
 #pragma unroll
@@ -246,7 +302,7 @@ template <int EPL> __device__ __forceinline__ float dotE(const float (&a)[EPL], 
 template <typename T, int DH, int FMAX, int EPL>
 __global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         T* __restrict__ out, int B, int F, int P, int heads,
-                                                        float scale, long ldqk, long ldv) {
+                                                        float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int CL = DH / EPL, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -270,14 +326,20 @@ __global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ q
             loadE<EPL>(v + m * ldv + col, vv[f]);
         }
     }
-    float qn[EPL];
+    if (diff) frame_diff_rows1<FMAX, EPL>(k, F);
+    float qn[EPL], qraw[EPL];
     loadE<EPL>(qk + row0 * ldqk + col, qn);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qraw[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < FMAX; ++i) {
         if (i < F) {
             float q[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) q[e] = qn[e];
+            for (int e = 0; e < EPL; ++e) {
+                q[e] = (diff && i >= 2) ? qn[e] - qraw[e] : qn[e];
+                qraw[e] = qn[e];
+            }
             if (i + 1 < F) loadE<EPL>(qk + (row0 + (long)(i + 1) * P) * ldqk + col, qn);     // one frame ahead
             float s[FMAX];
             float mx = -INFINITY;
@@ -307,7 +369,7 @@ __global__ __launch_bounds__(256) void tattn_fwd2_kernel(const T* __restrict__ q
             }
             if (valid) {
                 const long m = row0 + (long)i * P;
-                storeE<EPL>(out + m * ldv + col, o);
+                storeE<EPL>(out + m * ldo + col, o);
             }
         }
     }
@@ -319,7 +381,7 @@ template <typename T, int DH, int FMAX, int EPL, bool HOLD = false>
 __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ qk, const T* __restrict__ v,
                                                         const T* __restrict__ dout, T* __restrict__ dqk,
                                                         T* __restrict__ dv, int B, int F, int P, int heads,
-                                                        float scale, long ldqk, long ldv) {
+                                                        float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int CL = DH / EPL, GW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const long ngroups = (long)B * P * heads;
@@ -345,20 +407,24 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
             for (int e = 0; e < EPL; ++e) { dk[f][e] = 0.f; dvv[f][e] = 0.f; }
         }
     }
+    if (diff) frame_diff_rows1<FMAX, EPL>(k, F);
     constexpr int NH = HOLD ? FMAX : 1;
     float qa[NH][EPL], da[NH][EPL];
-    float qn[EPL], don[EPL];
+    float qn[EPL], don[EPL], qraw[EPL], dq_held[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { qraw[e] = 0.f; dq_held[e] = 0.f; }
     if (HOLD) {
 #pragma unroll
         for (int f = 0; f < NH; ++f) {
             if (f < F) {
                 loadE<EPL>(qk + (row0 + (long)f * P) * ldqk + col, qa[f]);
-                loadE<EPL>(dout + (row0 + (long)f * P) * ldv + col, da[f]);
+                loadE<EPL>(dout + (row0 + (long)f * P) * ldo + col, da[f]);
             }
         }
+        if (diff) frame_diff_rows1<NH, EPL>(qa, F);
     } else {
         loadE<EPL>(qk + row0 * ldqk + col, qn);
-        loadE<EPL>(dout + row0 * ldv + col, don);
+        loadE<EPL>(dout + row0 * ldo + col, don);
     }
 #pragma unroll
     for (int i = 0; i < FMAX; ++i) {
@@ -370,10 +436,14 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
                 for (int e = 0; e < EPL; ++e) { q[e] = qa[HOLD ? i : 0][e]; dO[e] = da[HOLD ? i : 0][e]; }
             } else {
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) { q[e] = qn[e]; dO[e] = don[e]; }
+                for (int e = 0; e < EPL; ++e) {
+                    q[e] = (diff && i >= 2) ? qn[e] - qraw[e] : qn[e];
+                    qraw[e] = qn[e];
+                    dO[e] = don[e];
+                }
                 if (i + 1 < F) {                                               // one frame ahead
                     loadE<EPL>(qk + (m + P) * ldqk + col, qn);
-                    loadE<EPL>(dout + (m + P) * ldv + col, don);
+                    loadE<EPL>(dout + (m + P) * ldo + col, don);
                 }
             }
             // probabilities are recomputed exactly as the forward computes them (max, exp, sum,
@@ -414,8 +484,24 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
                     }
                 }
             }
-            if (valid) storeE<EPL>(dqk + m * ldqk + col, dq);
+            if (!diff) {
+                if (valid) storeE<EPL>(dqk + m * ldqk + col, dq);
+            } else {
+                if (i >= 1) {
+                    if (i >= 2) {
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) dq_held[e] -= dq[e];
+                    }
+                    if (valid) storeE<EPL>(dqk + (m - P) * ldqk + col, dq_held);
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dq_held[e] = dq[e];
+            }
         }
+    }
+    if (diff) {
+        if (valid) storeE<EPL>(dqk + (row0 + (long)(F - 1) * P) * ldqk + col, dq_held);
+        frame_diff_adjoint_rows<FMAX, EPL>(dk, F);
     }
     if (valid) {
 #pragma unroll
@@ -443,47 +529,47 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
         else return ISTVT_ERR_SHAPE;                                                                     \
     } while (0)
 
-extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, void* out, long ldv, int B, int F,
-                                       int P, int heads, int dh, float scale, int dtype, hipStream_t stream) {
+extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, long ldv, void* out, long ldo, int B, int F,
+                                       int P, int heads, int dh, float scale, int diff, int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldqk % 8 || ldv % 8) return ISTVT_ERR_SHAPE;
-    static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
+    if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldo < (long)heads * dh || ldqk % 8 || ldv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
+    static const int use_mfma = istvt_tune("ISTVT_TATTN_MFMA", 1);
     if (use_mfma && dtype == DT_BF16 && F <= 32 && (dh == 64 || dh == 32)) {     // one wavefront per (b, p, h), MFMA tiles
         const long nprob = (long)B * P * heads;
         dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
-#define TATTN_F(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale, ldqk, ldv)
+#define TATTN_F(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale, ldqk, ldv, ldo, diff)
         if (dh == 64) { if (F <= 16) TATTN_F(64, 1); else TATTN_F(64, 2); }
         else { if (F <= 16) TATTN_F(32, 1); else TATTN_F(32, 2); }
 #undef TATTN_F
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, tattn_fwd2_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P,
-                                         heads, scale, ldqk, ldv));
+                                         heads, scale, ldqk, ldv, ldo, diff));
     return istvt_check_launch();
 }
 
-extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, const void* dout, void* dqk, void* dv,
-                                       long ldv, int B, int F, int P, int heads, int dh, float scale, int dtype,
-                                       hipStream_t stream) {
+extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, long ldv, const void* dout, long ldo,
+                                       void* dqk, void* dv, int B, int F, int P, int heads, int dh, float scale, int diff,
+                                       int dtype, hipStream_t stream) {
     if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
-    if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldqk % 8 || ldv % 8) return ISTVT_ERR_SHAPE;
-    static const int use_mfma = getenv("ISTVT_TATTN_MFMA") ? atoi(getenv("ISTVT_TATTN_MFMA")) : 1;
+    if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldo < (long)heads * dh || ldqk % 8 || ldv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
+    static const int use_mfma = istvt_tune("ISTVT_TATTN_MFMA", 1);
     // measured at C2 / C4 (tools/tattn_bench.py): F = 9 lane-cluster 170 us vs MFMA 203 us (its three 32-row LDS images
     // allow 8 wavefronts per CU); F = 17 850 us vs 336 us
-    static const int mfma_bwd_min = getenv("ISTVT_TATTN_MFMA_BWD_MINF") ? atoi(getenv("ISTVT_TATTN_MFMA_BWD_MINF")) : 1;
+    static const int mfma_bwd_min = istvt_tune("ISTVT_TATTN_MFMA_BWD_MINF", 1);
     if (use_mfma && dtype == DT_BF16 && F >= mfma_bwd_min && F <= 32 && (dh == 64 || dh == 32)) {
         const long nprob = (long)B * P * heads;
         long nwg = (nprob + 3) / 4;
         const long resident = 256L * (F <= 16 ? 4 : 2);      // workgroups per CU by registers (105 / 213 VGPRs at dh 64)
         if (nwg > resident) nwg = resident;                   // wavefronts loop over problems
         dim3 grid((unsigned)nwg), block(256);
-#define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale, ldqk, ldv)
+#define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale, ldqk, ldv, ldo, diff)
         if (dh == 64) { if (F <= 16) TATTN_B(64, 1); else TATTN_B(64, 2); }
         else { if (F <= 16) TATTN_B(32, 1); else TATTN_B(32, 2); }
 #undef TATTN_B
         return istvt_check_launch();
     }
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, tattn_bwd2_kernel, (const T*)qk, (const T*)v, (const T*)dout,
-                                         (T*)dqk, (T*)dv, B, F, P, heads, scale, ldqk, ldv));
+                                         (T*)dqk, (T*)dv, B, F, P, heads, scale, ldqk, ldv, ldo, diff));
     return istvt_check_launch();
 }

@@ -84,13 +84,64 @@ __device__ __forceinline__ void stage32(bf16_t* img, const bf16_t* __restrict__ 
         *reinterpret_cast<bf16x8*>(img + row * LDI + col) = row_frag(src, rstride, row, nrows, col);
     }
 }
+// ---- the frame difference of module.py:193 on projected rows (see attn_temporal.hip) ---------------------------------
+// Fragment layout: lane (g, r) holds row 16 t + r of a tile.  Row r - 1 is lane r - 1 of the same 16-lane DPP row
+// (row_shr:1); lane r = 0 receives row 15 of the tile BELOW (row_ror:1 of that tile's fragment).
+__device__ __forceinline__ bf16x8 prev_row_frag(const bf16x8& cur, const bf16x8& below) {
+    const u32x4 c = __builtin_bit_cast(u32x4, cur), b = __builtin_bit_cast(u32x4, below);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned wrap = __builtin_amdgcn_update_dpp(0u, b[i], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
+        o[i] = __builtin_amdgcn_update_dpp(wrap, c[i], 0x111 /* row_shr:1: lane 0 keeps `wrap` */, 0xf, 0xf, false);
+    }
+    return __builtin_bit_cast(bf16x8, o);
+}
+// x'[f] = x[f] - x[f-1] for f >= 2 (rounded once to bf16, the MFMA operand type)
+__device__ __forceinline__ bf16x8 diff_frag(const bf16x8& cur, const bf16x8& prev, const int f) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f >= 2 ? (bf16_t)((float)cur[i] - (float)prev[i]) : cur[i];
+    return o;
+}
+// accumulator layout: lane (g, r) holds row 16 u + r.  Row r + 1 is lane r + 1 (row_shl:1); lane 15 receives row 0 of
+// the tile ABOVE.  The adjoint of the difference: d x[f] = d x'[f] - d x'[f+1] for f + 1 >= 2.
+__device__ __forceinline__ f32x4 diff_adjoint_acc(const f32x4& cur, const f32x4& above, const int f) {
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned wrap = __builtin_amdgcn_update_dpp(0u, __float_as_uint(above[i]), 0x12F /* row_ror:15 */, 0xf, 0xf, true);
+        const unsigned nx = __builtin_amdgcn_update_dpp(wrap, __float_as_uint(cur[i]), 0x101 /* row_shl:1: lane 15 keeps `wrap` */, 0xf, 0xf, false);
+        o[i] = f >= 1 ? cur[i] - __uint_as_float(nx) : cur[i];
+    }
+    return o;
+}
+// the difference applied in place to a staged [16 NTL][DH + IPAD] image (one wavefront): every lane holds its 8-element
+// chunk of row `row` in `mine` (as staged), reads the chunk of the row above it in the frame order from the image,
+// and -- after every lane has read -- overwrites its own
+template <int DH, int NTL>
+__device__ __forceinline__ void diff_image(bf16_t* img, const bf16x8 (&mine)[16 * NTL / (64 / (DH / 8))], int lane) {
+    constexpr int LDI = DH + IPAD, VPR = DH / 8, RPI = 64 / VPR, NIT = 16 * NTL / RPI;
+    bf16x8 prev[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
+        prev[it] = *reinterpret_cast<const bf16x8*>(img + (row >= 1 ? row - 1 : 0) * LDI + col);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
+        *reinterpret_cast<bf16x8*>(img + row * LDI + col) = diff_frag(mine[it], prev[it], row);
+    }
+}
 }  // namespace tmf
 
 // NTL = 16-row tiles that hold the F frames (1: F <= 16, 2: F <= 32)
 template <int DH, int NTL>
 __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              bf16_t* __restrict__ out, int B, int F, int P, int heads,
-                                                             float scale, long ldqk, long ldv) {
+                                                             float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][16 * NTL * LDI];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
@@ -100,11 +151,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     const long bp = prob / heads, b = bp / P, p = bp % P;
     const int inner = heads * DH;
     const long row0 = b * F * P + p;
-    const long sq = (long)P * ldqk, sv = (long)P * ldv;
+    const long sq = (long)P * ldqk, sv = (long)P * ldv, so = (long)P * ldo;
     const bf16_t* qp = qk + row0 * ldqk + h * DH;
     const bf16_t* kp = qp + inner;
     const bf16_t* vp = v + row0 * ldv + h * DH;
-    bf16_t* op = out + row0 * ldv + h * DH;
+    bf16_t* op = out + row0 * ldo + h * DH;
     bf16_t* Vimg = smem[wave];
     const float c = scale * TM_LOG2E;
 
@@ -114,14 +165,32 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
+    if (diff) {                                             // top tile first: the tile below is still un-differenced
+#pragma unroll
+        for (int t = NTL - 1; t >= 0; --t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kf[t][ks] = tmf::diff_frag(kf[t][ks], tmf::prev_row_frag(kf[t][ks], kf[t > 0 ? t - 1 : 0][ks]), 16 * t + r);
+    }
     tmf::wave_lds_fence();
 
+    bf16x8 qbelow[KS];                                      // the un-differenced query rows of the previous tile
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qbelow[ks] = tmf::zero8();
 #pragma unroll
     for (int u = 0; u < NTL; ++u) {
         if (16 * u >= F) break;
         bf16x8 qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = tmf::row_frag(qp, sq, 16 * u + r, F, 32 * ks + 8 * g);
+        if (diff) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 raw = qf[ks];
+                qf[ks] = tmf::diff_frag(raw, tmf::prev_row_frag(raw, qbelow[ks]), 16 * u + r);
+                qbelow[ks] = raw;
+            }
+        }
         f32x4 s[2];
         s[1] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -159,7 +228,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
             tmf::mma_frames<NTL>(o, Vimg, LDI, 16 * dt, g, r, s[0], s[1]);
             if (q < F) {
                 float ov[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
-                store4(op + (long)q * sv + 16 * dt + 4 * g, ov);
+                store4(op + (long)q * so + 16 * dt + 4 * g, ov);
             }
         }
     }
@@ -169,7 +238,7 @@ template <int DH, int NTL>
 __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqk,
                                                              bf16_t* __restrict__ dv, int B, int F, int P, int heads,
-                                                             float scale, long ldqk, long ldv) {
+                                                             float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
     constexpr int IMG = 16 * NTL * LDI;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * IMG];
@@ -179,7 +248,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     long prob = (long)blockIdx.x * 4 + wave;
     if (prob >= total) return;                            // no workgroup-level synchronisation below
     const int inner = heads * DH;
-    const long sq = (long)P * ldqk, sv = (long)P * ldv;
+    const long sq = (long)P * ldqk, sv = (long)P * ldv, so = (long)P * ldo;
     bf16_t* Qimg = smem[wave];
     bf16_t* Kimg = Qimg + IMG;
     bf16_t* Dimg = Kimg + IMG;
@@ -197,13 +266,13 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         const bf16_t* qp = qk + row0 * ldqk + h * DH;
         const bf16_t* kp = qp + inner;
         const bf16_t* vp = v + row0 * ldv + h * DH;
-        const bf16_t* dop = dout + row0 * ldv + h * DH;
+        const bf16_t* dop = dout + row0 * ldo + h * DH;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
             nq[it] = tmf::row_frag(qp, sq, row, F, col);
             nk[it] = tmf::row_frag(kp, sq, row, F, col);
-            nd[it] = tmf::row_frag(dop, sv, row, F, col);
+            nd[it] = tmf::row_frag(dop, so, row, F, col);
         }
 #pragma unroll
         for (int t = 0; t < NTL; ++t)
@@ -232,6 +301,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) vf[t][ks] = nv[t][ks];
     tmf::wave_lds_fence();
+    if (diff) {                                           // Q, K images -> differenced in place (nq / nk still hold the rows)
+        tmf::diff_image<DH, NTL>(Qimg, nq, lane);
+        tmf::diff_image<DH, NTL>(Kimg, nk, lane);
+        tmf::wave_lds_fence();
+    }
     if (prob + nwaves < total) fetch(prob + nwaves);
     // K rows in fragment layout (row 16t + r, columns 32ks + 8g), from the image
 #pragma unroll
@@ -241,9 +315,12 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
             kf[t][ks] = *reinterpret_cast<const bf16x8*>(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
 
     // ---- part 1: per query tile u -- S^T, dP^T (keys on rows, queries on lanes), statistics, dQ
+    f32x4 above[DT];                                      // diff: d q' of the tile above (its row 0 closes row 15 below)
 #pragma unroll
-    for (int u = 0; u < NTL; ++u) {
-        if (16 * u >= F) break;
+    for (int dt = 0; dt < DT; ++dt) above[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = NTL - 1; u >= 0; --u) {
+        if (16 * u >= F) continue;
         const int q = 16 * u + r;
         bf16x8 qf[KS], dof[KS];
 #pragma unroll
@@ -298,6 +375,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         for (int dt = 0; dt < DT; ++dt) {
             f32x4 dq = f32x4{0, 0, 0, 0};
             tmf::mma_frames<NTL>(dq, Kimg, LDI, 16 * dt, g, r, s[0], s[1]);
+            if (diff) {                                   // rows >= F carry zero gradients (their dO rows are zero)
+                const f32x4 raw = dq;
+                dq = tmf::diff_adjoint_acc(raw, above[dt], q);
+                above[dt] = raw;
+            }
             if (q < F) {
                 float o[4] = {dq[0], dq[1], dq[2], dq[3]};
                 store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
@@ -309,8 +391,10 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     // ---- part 2: per key tile kt -- S, dP (queries on rows, keys on lanes) -> dV, dK
     // B operands of this orientation are the K / V rows of the tile: kf[kt], vf[kt] as loaded above
 #pragma unroll
-    for (int kt = 0; kt < NTL; ++kt) {
-        if (16 * kt >= F) break;
+    for (int dt = 0; dt < DT; ++dt) above[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kt = NTL - 1; kt >= 0; --kt) {
+        if (16 * kt >= F) continue;
         const int key = 16 * kt + r;
         f32x4 s[2], dp[2];
         s[1] = f32x4{0, 0, 0, 0}; dp[1] = f32x4{0, 0, 0, 0};
@@ -343,6 +427,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
             f32x4 dvv = f32x4{0, 0, 0, 0}, dkk = f32x4{0, 0, 0, 0};
             tmf::mma_frames<NTL>(dvv, Dimg, LDI, 16 * dt, g, r, s[0], s[1]);
             tmf::mma_frames<NTL>(dkk, Qimg, LDI, 16 * dt, g, r, dp[0], dp[1]);
+            if (diff) {
+                const f32x4 raw = dkk;
+                dkk = tmf::diff_adjoint_acc(raw, above[dt], key);
+                above[dt] = raw;
+            }
             if (key < F) {
                 float a[4] = {dkk[0], dkk[1], dkk[2], dkk[3]}, bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
                 store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);

@@ -42,6 +42,19 @@ __device__ __forceinline__ int xcd_chunk(const int id, const int nwg) {
 // weight gradients launched together by istvt_wgrad_group (gemm256t.h)
 constexpr int ISTVT_WGRAD_GROUP_MAX = 8;
 
+// Launch-geometry constants (grid caps, band widths, tile heights) were each swept on the MI355X; the value and the
+// measurement stand at the use.  The shipped library compiles them in.  A -DISTVT_TUNE build (tools/build_variant.sh)
+// reads the named environment variable instead, so a sweep is one build and one process per value.
+#ifdef ISTVT_TUNE
+#include <cstdlib>
+static inline long istvt_tune(const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v ? atol(v) : dflt;
+}
+#else
+static inline constexpr long istvt_tune(const char*, long dflt) { return dflt; }
+#endif
+
 static inline int istvt_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ISTVT_OK : -(1000 + (int)e);

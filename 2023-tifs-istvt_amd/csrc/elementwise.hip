@@ -47,7 +47,7 @@ extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, i
     if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0) return ISTVT_ERR_SHAPE;
     // 256 row blocks: every block ends with one float atomic per column into the SAME N addresses, and same-address
     // atomics serialise at the memory side (1024 row blocks were slower than 256 although the loads ran faster)
-    static const long rb = getenv("ISTVT_COLSUM_ROWBLOCKS") ? atol(getenv("ISTVT_COLSUM_ROWBLOCKS")) : 256;
+    static const long rb = istvt_tune("ISTVT_COLSUM_ROWBLOCKS", 256);
     int rpb = (int)((M + rb - 1) / rb);
     if (rpb < 64) rpb = 64;
     dim3 grid((N + 511) / 512, (unsigned)((M + rpb - 1) / rpb)), block(256);

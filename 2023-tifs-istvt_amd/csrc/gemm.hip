@@ -35,6 +35,7 @@ struct GemmArgs {
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
     int gm;               // gemm256q: row-panels per tile group (L2 locality of the tile walk)
     int band;             // gemm256q: > 0: column bands of this many tiles instead (wide outputs, see tile_origin)
+    int walk;             // gemm256q: 0 = XCD-contiguous eighths of the (group, row, column) list, 1 = row-panel slab per XCD
     double* st_sum;       // gemm256q<.., STATS = 1>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
     double* st_sumsq;     //   (double[R][2][N] accumulators of stem.hip; train-mode BatchNorm statistics of a 1x1 conv)
                           // gemm256q<.., STATS = 2>: st_sum only (a bias gradient; folded by istvt_stats_reduce_add)
@@ -295,7 +296,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     if (splitk > 1 && out_mode < 2) return ISTVT_ERR_SHAPE;        // split-K needs atomics (2) or partial slabs (3)
     const int esz = dtype == DT_F32 ? 4 : 2;
     const int bk = dtype == DT_F32 ? 32 : 64;
-    GemmArgs a;
+    GemmArgs a{};
     a.A = A; a.B = B; a.C = C; a.C2 = C2; a.bias = bias; a.residual = residual;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.epi = epi;
     a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
@@ -307,7 +308,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         // column bands for wide outputs (tile_origin in gemm256q.h).  Measured in the model at N = 2912 (12 column tiles):
         // bands of 6 tiles: GELU-forward GEMM 4.12 -> 3.96 ms per step, GELU-backward 4.05 -> 3.98; bands of 3: -3 % / +1.5 %;
         // bands of 2 or 4: the plain epilogue gains 7..9 %, the two GELU epilogues lose 8..16 %.  ISTVT_GEMM_BAND overrides.
-        static const int band_env = getenv("ISTVT_GEMM_BAND") ? atoi(getenv("ISTVT_GEMM_BAND")) : 6;
+        static const int band_env = istvt_tune("ISTVT_GEMM_BAND", 6);
         const int tn = (N + T256 - 1) / T256;
         a.band = tn >= 8 ? band_env : 0;
     }
@@ -353,16 +354,40 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 }
                 return G;
             };
+            // The tile walk (gemm256q.h): row-panel slabs per XCD for the tall GEMMs of the model, the XCD-contiguous list
+            // walk for everything else (few row panels; the BatchNorm-statistics epilogue, which wants to stay on one
+            // column tile as long as possible).
+            const int tiles_m256 = (M + T256 - 1) / T256;
+            // Measured (tools/gemm_q_sweep.py + rocprofv3 --pmc FETCH_SIZE, M = 56 736): the slab walk fetches 10-22 % fewer
+            // bytes than the list walk on the plain / residual epilogues (N = 1536, K = 728: 264 -> 212 MB per launch;
+            // N = 728, K = 2912: 534 -> 461) and 2-5 % MORE on the two GELU epilogues (N = 2912 column bands); launch time
+            // and the step are the same within the run-to-run noise either way (diagnostic builds that serve every A
+            // panel from L2 are only 0-5 % faster: the K loop is not bound by where the operands come from).
+            static const int walk_env = istvt_tune("ISTVT_GEMM_WALK", 1), gm_env = istvt_tune("ISTVT_GEMM_GM", -1),
+                             g_env = istvt_tune("ISTVT_GEMM_G", 0);
+            const bool slab = walk_env == 1 && tiles_m256 >= 64 && !col_sumsq && epi == EPI_NONE;
+            auto pick_grid = [&](int ntiles, int tm_rows) {
+                if (!slab) return balanced(ntiles);
+                // slab walk: the XCD with the most row panels sets the rounds; as few workgroups per XCD as fill them
+                const int tiles_m = (M + tm_rows - 1) / tm_rows, tiles_n = (N + T256 - 1) / T256;
+                const int per_xcd = ((tiles_m + 7) / 8) * tiles_n, cux = cus / 8;
+                const int rounds = (per_xcd + cux - 1) / cux;
+                int G = 8 * ((per_xcd + rounds - 1) / rounds);
+                a.walk = 1;
+                a.gm = gm_env > 0 ? gm_env : 1;
+                if (g_env > 0) G = g_env & ~7;
+                return G;
+            };
 #ifdef ISTVT_GEMM_DIAG
-            static const int qdbg = getenv("ISTVT_GEMM_QDBG") ? atoi(getenv("ISTVT_GEMM_QDBG")) : 0;
+            static const int qdbg = istvt_tune("ISTVT_GEMM_QDBG", 0);
             if (qdbg && epi == 0 && !residual) {
-                const int G = balanced(tiles);
+                const int G = pick_grid(tiles, 256);
+#define QD(n) case n: hipLaunchKernelGGL((gemm256q_kernel<0, false, n>), dim3(G), block, 0, stream, a); break;
                 switch (qdbg) {
-                    case 1: hipLaunchKernelGGL((gemm256q_kernel<0, false, 1>), dim3(G), block, 0, stream, a); break;
-                    case 2: hipLaunchKernelGGL((gemm256q_kernel<0, false, 2>), dim3(G), block, 0, stream, a); break;
-                    case 4: hipLaunchKernelGGL((gemm256q_kernel<0, false, 4>), dim3(G), block, 0, stream, a); break;
-                    default: hipLaunchKernelGGL((gemm256q_kernel<0, false, 8>), dim3(G), block, 0, stream, a); break;
+                    QD(1) QD(2) QD(4) QD(6) QD(8) QD(16) QD(22) QD(24) QD(48) QD(54) QD(128) QD(136) QD(129)
+                    default: return ISTVT_ERR_SHAPE;
                 }
+#undef QD
                 return istvt_check_launch();
             }
 #endif
@@ -372,18 +397,18 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             // N=728/K=2912 +2 %, N=512/K=728 +2.5 %, the GELU epilogue GEMMs -5..-8 %, the step +0.5 ms.  Off by
             // default: ISTVT_GEMM_TM=224 forces it (tests/test_model_gpu.py runs the GEMM checks that way), =-1 picks
             // by rounds x height.
-            static const int tm_env = getenv("ISTVT_GEMM_TM") ? atoi(getenv("ISTVT_GEMM_TM")) : 0;
+            static const int tm_env = istvt_tune("ISTVT_GEMM_TM", 0);
             const int tiles224 = ((M + 223) / 224) * ((N + T256 - 1) / T256);
             const long cost256 = (long)((tiles + cus - 1) / cus) * 256, cost224 = (long)((tiles224 + cus - 1) / cus) * 224;
             if (!col_sum && (tm_env == 224 || (tm_env == -1 && cost224 < cost256))) {
-                const dim3 grid(balanced(tiles224));
+                const dim3 grid(pick_grid(tiles224, 224));
                 if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false, 0, 224>), grid, block, 0, stream, a);
                 else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 224>), grid, block, 0, stream, a);
                 else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true, 0, 224>), grid, block, 0, stream, a);
                 else hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 224>), grid, block, 0, stream, a);
                 return istvt_check_launch();
             }
-            const dim3 grid(balanced(tiles));
+            const dim3 grid(pick_grid(tiles, 256));
             if (col_sum && col_sumsq) { // fused column statistics: the plain epilogue only (the stem's 1x1 convolutions)
                 if (epi != EPI_NONE || residual) return ISTVT_ERR_SHAPE;
                 hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 256, 1>), grid, block, 0, stream, a);

@@ -11,7 +11,7 @@
 // The LDS-DMA is priced per cache line touched in the CU's address path, not per byte and not by latency (ring
 // depth changes nothing): a 64-byte piece of a 1456-byte-stride row touches up to two lines for half a line of
 // data, and a 256x256 tile needs 19.6 TB/s of staging at the MFMA peak.  Hence whole 128-byte lines per row and
-// step (BK = 64) and operands with line-aligned row strides (ops.py pads 728 -> 768, 2912 -> 2944).
+// step (BK = 64) and operands with line-aligned row strides of an odd line count (ops.pad_ld: 728 -> 832, 2912 -> 3008).
 // In-kernel stamps of the first version (16-MFMA slots) then showed the slot, not the DMA, as the limit: a slot
 // took ~445 cycles for 256 cycles of MFMA because ONE in-order wavefront needs ~5 cycles per instruction and the
 // load slot carried ~45 of them plus the barrier round trip; so the slots are now 32 MFMA deep and the producer
@@ -73,7 +73,8 @@ __device__ __forceinline__ void slot_barrier() {
 // Requires 16-byte aligned rows and operands
 // smaller than 2 GiB (32-bit buffer offsets).
 // DBG (diagnostic builds only, -DISTVT_GEMM_DIAG + ISTVT_GEMM_QDBG=n): 1 = no DMA inside the K loop, 2 = no MFMA,
-// 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2.
+// 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2, 16 / 32 = every
+// tile reads the FIRST A / B panel (all L2 hits: the staging rate without HBM misses), 128 = no output stores.
 // TM = rows of a C tile: 256, or 224 = AL unit (128 rows) + 96 rows of the AH unit (its last four DMA pieces are sent
 // out of range: no traffic, zeros in LDS, same instruction and vmcnt counts), phase B then runs 3 instead of 4 row tiles
 // (24 MFMA).  At M = 56 736 this turns 222 row tiles into 254: an N = 728 GEMM is 762 tiles = 2.98 rounds of 256 CUs of
@@ -107,11 +108,35 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const int tiles_n = (p.N + T256 - 1) / T256, tiles_m = (p.M + TM - 1) / TM;
     const int nwg = tiles_n * tiles_m;
     const int G = gridDim.x;
-    const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
     const int nkt = (p.K + 63) >> 6;
+    // ---- the tile walk ---------------------------------------------------------------------------------------------
+    // p.walk == 1 (slab walk; the host sends G % 8 == 0 and tiles_m >= 8): the hardware deals workgroup ids round-robin to
+    // the 8 XCDs (id & 7, speed only), each with its own 4 MiB L2.  XCD x owns a contiguous SLAB of row panels
+    // [sr0, sr0 + snr) x all column tiles and its G / 8 workgroups walk the slab's tiles in one shared order, workgroup
+    // j taking entries j, j + G/8, ...: what runs at any moment is a window of G/8 consecutive entries.  The order is
+    // column bands of p.band tiles (all of them when p.band == 0), inside a band groups of p.gm row panels, inside a
+    // group row-fastest -- so the column tiles of a row panel sit within gm * band entries of each other and its A rows
+    // are fetched from HBM once per band instead of once per column tile, and no A panel is ever shared by two XCDs.
+    const int sxcd = (int)blockIdx.x & 7, sj = (int)blockIdx.x >> 3, sG = G >> 3;
+    const int sq = tiles_m >> 3, srem = tiles_m & 7;
+    const int sr0 = sxcd * sq + min(sxcd, srem), snr = sq + (sxcd < srem ? 1 : 0);
+    const int my_tiles = p.walk == 1 ? max(0, (snr * tiles_n - sj + sG - 1) / sG) : (nwg - (int)blockIdx.x + G - 1) / G;
     const int total_u = my_tiles * nkt * 4;
 
     auto tile_origin = [&](int i, int& bm0, int& bn0) {
+        if (p.walk == 1) {
+            const int e = sj + i * sG;
+            const int bw = p.band > 0 ? min(p.band, tiles_n) : tiles_n, nb = (tiles_n + bw - 1) / bw;
+            const int b = min(e / (snr * bw), nb - 1);
+            const int el = e - b * snr * bw, wb = min(bw, tiles_n - b * bw);
+            const int gm = p.gm > 0 ? p.gm : 1;
+            const int grp = el / (gm * wb), idl = el - grp * gm * wb;
+            const int rows_here = min(gm, snr - grp * gm);
+            // (integer division runs on the vector ALU: hand the results back as scalars, the DMA's scalar offsets need them)
+            bm0 = __builtin_amdgcn_readfirstlane((sr0 + grp * gm + idl % rows_here) * TM);
+            bn0 = __builtin_amdgcn_readfirstlane((b * bw + idl / rows_here) * T256);
+            return;
+        }
         int id = (int)blockIdx.x + i * G;
         const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
         id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
@@ -159,8 +184,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     auto p_setup = [&](int i) {
         int bm0, bn0;
         tile_origin(i, bm0, bn0);
-        a_org = bm0 * lda * 2;
-        b_org = bn0 * ldb * 2;
+        a_org = (DBG & 16) ? 0 : bm0 * lda * 2;        // DBG 16 / 32: every tile streams the first A / B panel (L2 hits only)
+        b_org = (DBG & 32) ? 0 : bn0 * ldb * 2;
     };
     // units P, P+1 of K tile p_s: J0 = 0 -> (AL, BL), J0 = 2 -> (BH, AH)
     auto issue_pair = [&](const int J0) {
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = lo[j] * alpha; v[4 + j] = hi[j] * alpha; }
-                const unsigned voff = rb < rows_left ? c_off : OOB;
+                const unsigned voff = (rb < rows_left && !(DBG & 128)) ? c_off : OOB;      // DBG 128: no output stores
                 const int soff = rb * ldc * 2;
                 if (EPI == EPI_GELU_BWD) {
                     const bf16x8 u = __builtin_bit_cast(bf16x8, sv[pass * 2 + it]);

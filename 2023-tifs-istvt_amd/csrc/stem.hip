@@ -109,7 +109,7 @@ __device__ __forceinline__ void colreduce_block(F f, double* const (&out)[NACC],
 
 static void colreduce_grid(long M, int C, dim3& grid, int& rpb) {
     const int gx = (C / 8 + 255) / 256;
-    static const long wg_target = getenv("ISTVT_COLRED_BLOCKS") ? atol(getenv("ISTVT_COLRED_BLOCKS")) : 512;   // 2048: +0.6 ms per step (fp64 atomics tail per workgroup); 256: +0.03
+    static const long wg_target = istvt_tune("ISTVT_COLRED_BLOCKS", 512);   // 2048: +0.6 ms per step (fp64 atomics tail per workgroup); 256: +0.03
     long target = wg_target / gx;
     if (target < 1) target = 1;
     rpb = (int)((M + target - 1) / target);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const T* __restrict__ x, co
 }
 
 static int ew_grid(long nvec) {
-    static const long cap = getenv("ISTVT_EW_BLOCKS") ? atol(getenv("ISTVT_EW_BLOCKS")) : 65536;   // measured: 4096 -> 65536 workgroups = -6 % on the BN-backward apply, -4 % on the pools
+    static const long cap = istvt_tune("ISTVT_EW_BLOCKS", 65536);   // measured: 4096 -> 65536 workgroups = -6 % on the BN-backward apply, -4 % on the pools
     long b = (nvec + 255) / 256;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
@@ -337,7 +337,7 @@ extern "C" int istvt_bn_bwd_apply(const void* dz, const void* u, const float* bn
                                   float* dbeta, long M, int C, int batch_stats, int dtype, hipStream_t stream) {
     if (M <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     // few vectors per thread would load the per-channel constants as often as before: a grid of resident size
-    static const long bnb_cap = getenv("ISTVT_BNB_BLOCKS") ? atol(getenv("ISTVT_BNB_BLOCKS")) : 2048;   // sweep 1024 .. 16384: 2.04 .. 2.19 ms per step (flat); 65536: 2.56
+    static const long bnb_cap = istvt_tune("ISTVT_BNB_BLOCKS", 2048);   // sweep 1024 .. 16384: 2.04 .. 2.19 ms per step (flat); 65536: 2.56
     long bnb = (M * (C / 8) + 255) / 256;
     if (bnb > bnb_cap) bnb = bnb_cap;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3((unsigned)bnb), dim3(256), 0,
@@ -905,7 +905,7 @@ extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
     const int cy = (C + DW_CC - 1) / DW_CC;
-    static const long wg_cap = getenv("ISTVT_DWW_BLOCKS") ? atol(getenv("ISTVT_DWW_BLOCKS")) : 512;   // = resident workgroups; 2048 was 4 % slower (atomics tail per workgroup)
+    static const long wg_cap = istvt_tune("ISTVT_DWW_BLOCKS", 512);   // = resident workgroups; 2048 was 4 % slower (atomics tail per workgroup)
     long bx = wg_cap / cy;
     if (bx < 1) bx = 1;
     if (bx > tiles) bx = tiles;
@@ -1119,7 +1119,7 @@ extern "C" int istvt_pool_bwd(const void* dout, const uint8_t* argmax, void* dz,
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long nquads = (long)Fr * (H / 2 + 1) * (W / 2 + 1);      // 2x2 pixel quads, see the kernel
     // with the statistics every workgroup ends in 2 C fp64 atomics: a grid of resident size
-    static const long cap = getenv("ISTVT_POOLB_BLOCKS") ? atol(getenv("ISTVT_POOLB_BLOCKS")) : 2048;
+    static const long cap = istvt_tune("ISTVT_POOLB_BLOCKS", 2048);
     long blocks = (nquads * (C / 8) + 255) / 256;
     if (blocks > cap) blocks = cap;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,

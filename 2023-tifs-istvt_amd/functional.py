@@ -77,34 +77,10 @@ class LayerNormFn(Function):
         return dx, rg, rb, None, None, None
 
 
-class LayerNormDiffFn(Function):
-    """LayerNorm that also returns the frame difference of its output (module.py:193); fork as in LayerNormFn."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, eps, B, F, P, fork=False, sink=None):
-        y, diff, mean, rstd = ops.layernorm_fwd_diff(x, gamma, beta, eps, B, F, P, pad=True)
-        ctx.save_for_backward(x, mean, rstd, gamma, beta)
-        ctx.geom = (F, P)
-        ctx.set_materialize_grads(False)
-        ctx.sink = sink
-        return (y, diff, x.view_as(x)) if fork else (y, diff)
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy, ddiff, dres=None):
-        x, mean, rstd, gamma, beta = ctx.saved_tensors
-        F, P = ctx.geom
-        dg, rg = _target(gamma)
-        db, rb = _target(beta)
-        if dy is None:
-            dy = torch.zeros_like(ddiff if ddiff is not None else x)
-        dcol = ctx.sink.buffer() if ctx.sink is not None else None
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dy2=ddiff, dres=dres, F=F, P=P, pad=True, dcol=dcol)
-        return dx, rg, rb, None, None, None, None, None, None
-
-
 class FrameDiffFn(Function):
-    """residual = cat(x[:, :2], x[:, 2:] - x[:, 1:-1]) over frames (module.py:193)."""
+    """residual = cat(x[:, :2], x[:, 2:] - x[:, 1:-1]) over frames (module.py:193) as a pass of its own.  The model does
+    not use it (TemporalResidualAttention differences q and k inside the attention kernels); it is the reference-order
+    form the fused path is tested against."""
 
     @staticmethod
     def forward(ctx, x, B, F, P):
@@ -149,6 +125,19 @@ def join_side_stream(dev=None):
     if dev is None:
         dev = torch.cuda.current_device()
     _join_side(dev)
+
+
+def no_data_parallel(self):
+    """``nn.Module._replicate_for_data_parallel`` of every module in network/: the reference loop wraps the model in
+    single-process ``nn.DataParallel`` when ``-d`` names more than one device (train_CNN.py:185-186).  That mode cannot
+    work here -- replicas are shallow copies made per forward on worker THREADS, while the weight-operand cache
+    (ops._wcache), the side-stream join state and the flat gradient bucket are per process and keyed by the original
+    parameters -- so it fails at the first replication with the way out, instead of training on stale operands."""
+    raise RuntimeError(
+        '%s: torch.nn.DataParallel is not supported by the HIP path (per-process operand caches, side streams and the '
+        'flat gradient bucket).  Run one process per GPU instead: `python -m torch.distributed.run --nproc-per-node N '
+        '...` (torchrun) with istvt_amd.parallel.GradBucket.all_reduce() after backward, as bench.py --gpus N does; '
+        'per-rank BatchNorm statistics then match what DataParallel would have computed.' % type(self).__name__)
 
 
 # Callables run by TokensFn.backward once its own kernels are enqueued.  Token assembly is the first operation of the
@@ -207,18 +196,21 @@ def flush_stale_joins():
     end-of-backward callback: its join entry and the operands it keeps alive would stay behind, every later backward
     would skip registering a join and the optimizer would read weight gradients the side stream may still be writing.
     Called from the forward (outside any backward every entry is stale) and from _wgrad (an entry of another graph
-    task is stale): joins the side stream into the CURRENT stream and drops the entry; weight gradients of the
-    aborted pass that were still queued are dropped with it (its gradients are garbage anyway)."""
+    task is stale): launches whatever that pass still had queued, joins the side stream into the CURRENT stream and
+    drops the entry.  The queued weight gradients are LAUNCHED, not dropped: a foreign entry is not always an aborted
+    pass -- a re-entrant backward (torch.utils.checkpoint's recompute, a Function that calls backward) has a task id
+    of its own while the outer pass's gradients are still queued, and those must land.  (For a pass that really
+    aborted the extra launches only add to gradients that are garbage already and are zeroed before the next step.)"""
     if not _overlap['pending']:
         return
     task = _graph_task()
     for dev in list(_overlap['pending']):
         if task == -1 or _overlap['pending'][dev][1] != task:
+            _flush_group(dev)
             side = _overlap['streams'].get(dev)
             if side is not None:
                 torch.cuda.current_stream(torch.device('cuda', dev)).wait_stream(side)
             del _overlap['pending'][dev]
-            _overlap['queue'].pop(dev, None)
             _overlap['keep'].pop(dev, None)
 
 
@@ -303,6 +295,35 @@ class LinearFn(Function):
         return dx, dw, db, dres, None
 
 
+class LinearCatFn(Function):
+    """y = x [W_0; W_1; ...]^T: several bias-free nn.Linear layers over ONE input as one GEMM on the stacked operand
+    (ops.weight_cat_as); the parameters stay separate.  TemporalResidualAttention's to_qk and to_v (module.py:182-183,
+    195-196): one 728 -> 1536 projection, one packed input gradient, per-parameter weight gradients from the column
+    ranges of dy."""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        if _overlap['pending']:
+            flush_stale_joins()
+        w = ops.weight_cat_as(weights, x.dtype)
+        y = ops.linear_fwd(x, w, pad=True)
+        ctx.save_for_backward(x, *weights)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, *weights = ctx.saved_tensors
+        w = ops.weight_cat_as(weights, dy.dtype)
+        dx = ops.linear_dgrad(dy, w, pad=True) if ctx.needs_input_grad[0] else None
+        grads, n0 = [], 0
+        for i, wi in enumerate(weights):
+            n = wi.shape[0]
+            grads.append(_wgrad(dy[:, n0:n0 + n], x, wi) if ctx.needs_input_grad[1 + i] else None)
+            n0 += n
+        return (dx, *grads)
+
+
 class FeedForwardFn(Function):
     """Linear -> exact GELU -> Linear (+ residual) (FeedForward, module.py:23-34)."""
 
@@ -348,21 +369,27 @@ class SpatialAttnFn(Function):
 
 
 class TemporalAttnFn(Function):
-    """softmax(q k^T / sqrt(d)) v per (position, head) over frames (module.py:197-205)."""
+    """softmax(q k^T / sqrt(d)) v per (position, head) over frames (module.py:197-205) on ONE packed projection
+    qkv [M, 3 * inner] (q | k | v).  diff=True: q and k are differenced over frames inside the kernels (module.py:193:
+    TemporalResidualAttention projects the un-differenced LayerNorm output once; exact, to_qk has no bias).  The
+    backward returns ONE packed gradient with respect to the un-differenced projection."""
 
     @staticmethod
-    def forward(ctx, qk, v, B, F, P, heads, dh):
-        out = ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh)
-        ctx.save_for_backward(qk, v)
-        ctx.geom = (B, F, P, heads, dh)
+    def forward(ctx, qkv, B, F, P, heads, dh, diff):
+        inner = heads * dh
+        out = ops.attn_temporal_fwd(qkv[:, :2 * inner], qkv[:, 2 * inner:], B, F, P, heads, dh, diff=diff)
+        ctx.save_for_backward(qkv)
+        ctx.geom = (B, F, P, heads, dh, bool(diff))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        qk, v = ctx.saved_tensors
-        dqk, dv = ops.attn_temporal_bwd(qk, v, dout, *ctx.geom)
-        return dqk, dv, None, None, None, None, None
+        (qkv,) = ctx.saved_tensors
+        B, F, P, heads, dh, diff = ctx.geom
+        inner = heads * dh
+        dqkv, _ = ops.attn_temporal_bwd(qkv[:, :2 * inner], qkv[:, 2 * inner:], dout, B, F, P, heads, dh, diff=diff, packed=True)
+        return dqkv, None, None, None, None, None, None
 
 
 class TokensFn(Function):

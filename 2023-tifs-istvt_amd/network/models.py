@@ -71,3 +71,6 @@ def model_selection(modelname, num_out_classes, dropout=None, batch_size=16, **i
         return TransferModel(modelchoice='xception', num_out_classes=num_out_classes, **kw)
     return TransferModel(modelchoice=modelname, num_out_classes=num_out_classes, batch_size=batch_size,
                          **istvt_kwargs).get_model()
+
+
+TransferModel._replicate_for_data_parallel = _xception._Fn.no_data_parallel     # nn.DataParallel: see functional.no_data_parallel

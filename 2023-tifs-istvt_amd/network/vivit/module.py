@@ -49,11 +49,6 @@ class PreNorm(nn.Module):
         fork = kwargs.pop('fork', False)
         sink = kwargs.pop('sink', None)
         own_res = isinstance(kwargs.get('residual'), str) and kwargs['residual'] == 'input'
-        fused = getattr(self.fn, 'forward_prenorm', None)
-        if fused is not None:           # temporal attention: LayerNorm + frame difference in one kernel
-            if own_res:
-                raise NotImplementedError("residual='input' is not used with the temporal attention block")
-            return fused(x, self.norm, fork=fork, sink=sink, **kwargs)
         if fork or own_res:
             y, xr = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, fork=True, sink=sink)
             if own_res:
@@ -138,10 +133,17 @@ class TemporalResidualAttention(nn.Module):
             nn.Dropout(dropout)
         )
 
-    def _attend(self, xn, diff, b, n, hw, frames, residual, defer_bias=False):
-        qk = Fn.LinearFn.apply(diff, self.to_qk.weight, None, None)
-        v = Fn.LinearFn.apply(xn, self.to_v.weight, None, None)
-        out = Fn.TemporalAttnFn.apply(qk, v, b, frames, hw, self.heads, self.dim_head)
+    def forward(self, x, hw=None, residual=None, defer_bias=False):
+        # module.py:192-206.  The reference differences the LayerNorm output over frames (:193), projects the difference
+        # with to_qk and the un-differenced rows with to_v.  to_qk has no bias (:182), so to_qk(x[f] - x[f-1]) =
+        # to_qk(x[f]) - to_qk(x[f-1]): ONE GEMM on the stacked [to_qk | to_v] operand, and the temporal attention kernels
+        # difference q and k in registers (all frames of a position sit in one wavefront) -- no differenced copy of the
+        # activations, one input-gradient GEMM.
+        b, n, d = x.shape
+        hw = self.hw if hw is None else hw
+        frames = _frames(n, hw, 'TemporalResidualAttention')
+        qkv = Fn.LinearCatFn.apply(x.reshape(b * n, d), self.to_qk.weight, self.to_v.weight)
+        out = Fn.TemporalAttnFn.apply(qkv, b, frames, hw, self.heads, self.dim_head, True)
         proj = self.to_out[0]
         plain = self.to_out[1].p == 0.0 or not self.training
         r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
@@ -151,23 +153,6 @@ class TemporalResidualAttention(nn.Module):
             if residual is not None:
                 y = Fn.add(y, residual)
         return y
-
-    def forward(self, x, hw=None, residual=None, defer_bias=False):
-        b, n, d = x.shape
-        hw = self.hw if hw is None else hw
-        frames = _frames(n, hw, 'TemporalResidualAttention')
-        x2 = x.reshape(b * n, d)
-        diff = Fn.FrameDiffFn.apply(x2, b, frames, hw)
-        return self._attend(x2, diff, b, n, hw, frames, residual, defer_bias)
-
-    def forward_prenorm(self, x, norm, hw=None, residual=None, fork=False, sink=None, defer_bias=False):
-        """PreNorm(self)(x): LayerNorm and the frame difference come out of one kernel."""
-        b, n, d = x.shape
-        hw = self.hw if hw is None else hw
-        frames = _frames(n, hw, 'TemporalResidualAttention')
-        outs = Fn.LayerNormDiffFn.apply(x.reshape(b * n, d), norm.weight, norm.bias, norm.eps, b, frames, hw, fork, sink)
-        y = self._attend(outs[0], outs[1], b, n, hw, frames, residual, defer_bias)
-        return (y, outs[2].view(b, n, d)) if fork else y
 
 
 class Attention(nn.Module):
@@ -208,8 +193,7 @@ class Attention(nn.Module):
 class TemporalOnlyAttention(nn.Module):
     """Attention over the frame axis per (batch, head, position) from ONE packed to_qkv, no frame difference
     (reference module.py:145-172; its hard-coded ``hw = 19 * 19 + 1`` is the ``hw`` keyword).  The temporal
-    attention kernel takes q|k and v as two matrices: they come from two GEMMs over the two row blocks of
-    ``to_qkv.weight`` (views of the one parameter, so the state dict and the gradient are the reference's)."""
+    attention kernel takes q|k and v as column ranges of the one packed projection."""
 
     def __init__(self, dim, heads=8, dim_head=64, dropout=0., hw=19 * 19 + 1):
         super().__init__()
@@ -230,10 +214,8 @@ class TemporalOnlyAttention(nn.Module):
         frames = _frames(n, hw, 'TemporalOnlyAttention')
         inner = self.heads * self.dim_head
         x2 = x.reshape(b * n, d)
-        w = self.to_qkv.weight
-        qk = Fn.LinearFn.apply(x2, w[:2 * inner], None, None)
-        v = Fn.LinearFn.apply(x2, w[2 * inner:], None, None)
-        out = Fn.TemporalAttnFn.apply(qk, v, b, frames, hw, self.heads, self.dim_head)
+        qkv = Fn.LinearFn.apply(x2, self.to_qkv.weight, None, None)
+        out = Fn.TemporalAttnFn.apply(qkv, b, frames, hw, self.heads, self.dim_head, False)
         proj = self.to_out[0]
         plain = self.to_out[1].p == 0.0 or not self.training
         r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None
@@ -243,3 +225,7 @@ class TemporalOnlyAttention(nn.Module):
             if residual is not None:
                 y = Fn.add(y, residual)
         return y
+
+
+for _cls in (PreNorm, FeedForward, SpatialOnlyAttention, TemporalResidualAttention, Attention, TemporalOnlyAttention):
+    _cls._replicate_for_data_parallel = Fn.no_data_parallel      # nn.DataParallel: see functional.no_data_parallel

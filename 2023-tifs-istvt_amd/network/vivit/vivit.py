@@ -259,3 +259,7 @@ class VanillaTr(nn.Module):
         xs = Fn.PrependFn.apply(emb, self.cls_token, self.pos_embedding, 1)
         xs = self.transformer(xs)
         return _head(self.mlp_head, Fn.TakeFirstFn.apply(xs))
+
+
+for _cls in (Transformer, STTransformer, DSTTr, XceptionVidTr, ViViT, VanillaTr):
+    _cls._replicate_for_data_parallel = Fn.no_data_parallel      # nn.DataParallel: see functional.no_data_parallel

@@ -148,14 +148,15 @@ class Xception(nn.Module):
         """Reference signature (xception.py:193-206): (n,3,S,S) -> (n,728,h,w)."""
         return self.low_level_features_nhwc(input).permute(0, 3, 1, 2)
 
-    def features(self, input):
-        """reference xception.py:161-191: entry flow, blocks 4-12, conv3/bn3/relu/conv4/bn4 -> (n, 2048, h, w)."""
-        x = self.low_level_features_nhwc(input)                    # (n, h, w, 728), compute dtype
-        n, h, w, c = x.shape
-        x = x.view(n * h * w, c)
-        for i in range(4, 13):
+    def _blocks_nhwc(self, x, n, h, w, first, last):
+        """block<first> .. block<last> on NHWC rows [n*h*w, C] -> (rows, h, w)"""
+        for i in range(first, last + 1):
             x, h, w = getattr(self, 'block%d' % i).forward_nhwc(x, n, h, w)
-        # exit flow: Sep(1024->1536) BN ReLU Sep(1536->2048) BN as one chain whose last BatchNorm is materialised
+        return x, h, w
+
+    def _exit_nhwc(self, x, n, h, w):
+        """exit flow after block12: Sep(1024->1536) BN ReLU Sep(1536->2048) BN as one chain whose last BatchNorm is
+        materialised (xception.py:180-190; no ReLU after bn4)"""
         for m in (self.conv3, self.conv4):
             m._check()
         spec = _xb.ChainSpec([(self.conv3.conv1.in_channels, self.conv3.pointwise.out_channels),
@@ -167,6 +168,14 @@ class Xception(nn.Module):
         if self.training:
             self.bn3.num_batches_tracked.add_(1)
             self.bn4.num_batches_tracked.add_(1)
+        return x
+
+    def features(self, input):
+        """reference xception.py:161-191: entry flow, blocks 4-12, conv3/bn3/relu/conv4/bn4 -> (n, 2048, h, w)."""
+        x = self.low_level_features_nhwc(input)                    # (n, h, w, 728), compute dtype
+        n, h, w, c = x.shape
+        x, h, w = self._blocks_nhwc(x.view(n * h * w, c), n, h, w, 4, 12)
+        x = self._exit_nhwc(x, n, h, w)
         return _xb.nchw_view(x.view(n, h, w, -1))
 
     def logits(self, features):
@@ -238,3 +247,7 @@ def return_pytorch04_xception(pretrained=False, weights_path=None):
         model.last_linear = model.fc
         del model.fc
     return model
+
+
+for _cls in (SeparableConv2d, Block, Xception):
+    _cls._replicate_for_data_parallel = _Fn.no_data_parallel      # nn.DataParallel: see functional.no_data_parallel

@@ -55,15 +55,23 @@ def _stream() -> int:
 ROW_ALIGN = 64
 
 
-_PAD_MOD = tuple(int(v) for v in os.environ.get('ISTVT_PAD_MOD', '2,1').split(','))   # (m, r): lines per row = r mod m
+def _parse_pad_mod(spec: str) -> Tuple[int, int]:
+    try:
+        m, r = (int(v) for v in spec.split(','))
+    except ValueError:
+        raise ValueError("ISTVT_PAD_MOD must be 'm,r' (lines per row = r mod m), got %r" % (spec,)) from None
+    if m < 1 or not 0 <= r < m:
+        raise ValueError('ISTVT_PAD_MOD=%r: need m >= 1 and 0 <= r < m' % (spec,))
+    return m, r
+
+
+_PAD_MOD = _parse_pad_mod(os.environ.get('ISTVT_PAD_MOD', '2,1'))   # (m, r): 64-element units per row = r mod m
 
 
 def pad_ld(n: int) -> int:
     q = (n + ROW_ALIGN - 1) // ROW_ALIGN
     m, r = _PAD_MOD
-    while q % m != r:
-        q += 1
-    return q * ROW_ALIGN
+    return (q + ((r - q) % m)) * ROW_ALIGN
 
 
 def empty_rows(M: int, D: int, dtype, device, pad: bool = True) -> Tensor:
@@ -145,6 +153,47 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
     else:
         out = cast(w2, dtype)
     _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), (w._version, _wepoch[0]), out)
+    return out
+
+
+def weight_cat_as(ws, dtype: torch.dtype) -> Tensor:
+    """[w_0; w_1; ...] stacked along the output dimension as ONE line-aligned GEMM operand in the compute dtype: the
+    parameters stay separate (state dict, optimizer), the operand copy is cached until one of them is modified.
+    TemporalResidualAttention's [to_qk | to_v] (module.py:182-183): one 728 -> 1536 GEMM instead of two.  For bf16 the
+    operand of the input-gradient GEMM ([K, sum N_i], k-contiguous W^T) comes out of the same passes over the fp32
+    weights."""
+    ws = tuple(ws)
+    key = (tuple(id(w) for w in ws), 'cat')
+    ver = tuple(w._version for w in ws) + (_wepoch[0],)
+    hit = _wcache.get(key)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)) and hit[1] == ver and hit[2].dtype == dtype:
+        return hit[2]
+    K = ws[0].shape[1]
+    if any(w.dim() != 2 or w.shape[1] != K for w in ws):
+        raise RuntimeError('weight_cat_as: the weights must be 2-D with one input width')
+    R = sum(w.shape[0] for w in ws)
+    dev = ws[0].device
+    out = empty_rows(R, K, dtype, dev, K % 8 == 0)
+    fused_t = (dtype == torch.bfloat16 and all(w.dtype == torch.float32 and w.shape[0] % 8 == 0 and w.shape[0] >= G256_MIN
+                                                for w in ws) and K >= G256_MIN and K % 8 == 0)
+    wt = empty_rows(K, R, dtype, dev) if fused_t else None
+    r0 = 0
+    for w in ws:
+        w2 = _c(w.detach())
+        n = w2.shape[0]
+        if fused_t:
+            es = out.element_size()
+            _lib.check(_lib.lib().istvt_cast_transpose(w2.data_ptr(), K, out.data_ptr() + r0 * out.stride(0) * es, out.stride(0),
+                                                       wt.data_ptr() + r0 * es, wt.stride(0), n, K, _stream()),
+                       'istvt_cast_transpose')
+        else:
+            out[r0:r0 + n].copy_(w2)
+        r0 += n
+    if wt is not None:
+        tkey = (id(out), 'T')
+        _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey, c=_wcache: c.pop(k, None)), 0, wt)
+    drop = lambda _r, k=key, c=_wcache: c.pop(k, None)
+    _wcache[key] = (tuple(weakref.ref(w, drop) for w in ws), ver, out)
     return out
 
 
@@ -478,46 +527,30 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, pad: bool 
     return (y if x.dim() == 2 else y.view(*x.shape)), mean, rstd
 
 
-def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: int, F: int, P: int, pad: bool = False):
+def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
+                  dres: Optional[Tensor] = None, pad: bool = False, dcol: Optional[Tensor] = None) -> Tensor:
+    """dx of LayerNorm (+ dres, the gradient arriving through the residual fork); dgamma / dbeta (float32 [D]) accumulate;
+    dcol (float32 [D], optional) accumulates the column sums of dx (the producing Linear's bias gradient).  Row-strided
+    views allowed.  Reproducible: the column sums are reduced in a fixed order (per-workgroup partial rows + one
+    reduce launch), no atomics."""
     x2, ldx = rows(_req(x))
     M, D = x2.shape
-    if M != B * F * P:
-        raise RuntimeError('layernorm_fwd_diff: %s is not (B=%d, F*P=%d*%d, D)' % (tuple(x.shape), B, F, P))
-    y = empty_rows(M, D, x.dtype, x.device, pad)
-    diff = empty_rows(M, D, x.dtype, x.device, pad)
-    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
-    with prof('ln_fwd_diff', 3 * M * D * x.element_size()):
-        _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                                       y.stride(0), diff.data_ptr(), diff.stride(0), mean.data_ptr(),
-                                                       rstd.data_ptr(), B, F, P, D, eps, dtype_code(x), _stream()),
-                   'istvt_layernorm_fwd_diff')
-    return y, diff, mean, rstd
-
-
-def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
-                  dy2: Optional[Tensor] = None, dres: Optional[Tensor] = None, F: int = 1, P: int = 1,
-                  pad: bool = False, dcol: Optional[Tensor] = None) -> Tensor:
-    """dcol: float32 [D] buffer that receives (+=) the column sums of dx."""
-    x2, ldx = rows(x)
-    M, D = x2.shape
     dy, ld_dy = rows(_req(dy))
-    ld_dy2 = ld_res = 0
-    if dy2 is not None:
-        dy2, ld_dy2 = rows(dy2)
+    ld_res = 0
     if dres is not None:
         dres, ld_res = rows(dres)
     dx = empty_rows(M, D, x.dtype, x.device, pad)
-    ntens = 3 + (dy2 is not None) + (dres is not None)          # dy, x, dx (+ dy2 once: its shifted re-read hits L2) (+ dres)
+    lib = _lib.lib()
+    ws = torch.empty((lib.istvt_layernorm_bwd_ws_elems(M, D),), dtype=torch.float32, device=x.device)
+    ntens = 3 + (dres is not None)          # dy, x, dx (+ dres)
     with prof('ln_bwd', ntens * M * D * x.element_size()):
-        _lib.check(_lib.lib().istvt_layernorm_bwd(dy.data_ptr(), ld_dy, _ptr(dy2), ld_dy2, x2.data_ptr(), ldx, mean.data_ptr(),
-                                                  rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(),
-                                                  dx.stride(0) if M > 1 else D, dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dcol), M, D, F,
-                                                  P, dtype_code(x), _stream()), 'istvt_layernorm_bwd')
+        _lib.check(lib.istvt_layernorm_bwd(dy.data_ptr(), ld_dy, x2.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
+                                           gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(), dx.stride(0) if M > 1 else D,
+                                           dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dcol), ws.data_ptr(), ws.numel(), M, D,
+                                           dtype_code(x), _stream()), 'istvt_layernorm_bwd')
     return dx if x.dim() == 2 else dx.view(*x.shape)
 
 
-# ------------------------------------------------------------------------------------------
 def _same_rows(like: Tensor, ld: int, M: int, D: int) -> Tensor:
     """an uninitialised [M, D] tensor with row stride ld (the layout of a saved operand: its gradient shares it)"""
     buf = torch.empty((M, ld), dtype=like.dtype, device=like.device)
@@ -560,37 +593,48 @@ def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: in
     return dqkv
 
 
-def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int, dh: int):
-    """qk [B*F*P, 2*heads*dh], v [B*F*P, heads*dh] (row-strided views allowed) -> out with v's row stride"""
+def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int, dh: int, diff: bool = False):
+    """qk [B*F*P, 2*heads*dh], v [B*F*P, heads*dh] (row-strided views allowed: e.g. the two column ranges of one packed
+    q|k|v projection) -> out [B*F*P, heads*dh] with line-aligned rows.  diff: frame difference on q, k in the kernel
+    (TemporalResidualAttention, module.py:193)."""
     inner = heads * dh
     (qk, ldqk), (v, ldv) = rows(_req(qk)), rows(_req(v))
     if F > 17:
         raise RuntimeError('attn_temporal: at most 17 frames (T <= 16) are supported, got F=%d' % F)
     if tuple(qk.shape) != (B * F * P, 2 * inner) or tuple(v.shape) != (B * F * P, inner):
         raise RuntimeError('attn_temporal: shapes %s / %s do not match B=%d F=%d P=%d' % (tuple(qk.shape), tuple(v.shape), B, F, P))
-    out = _same_rows(v, ldv, B * F * P, inner)
+    out = empty_rows(B * F * P, inner, v.dtype, v.device)
+    ldo = out.stride(0)
     with prof('attn_temporal_fwd', 4 * B * F * P * inner * qk.element_size(), 4.0 * B * P * heads * F * F * dh):
-        _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), ldqk, v.data_ptr(), out.data_ptr(), ldv, B, F, P,
-                                                      heads, dh, dh ** -0.5, dtype_code(qk), _stream()),
+        _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), ldqk, v.data_ptr(), ldv, out.data_ptr(), ldo, B, F, P,
+                                                      heads, dh, dh ** -0.5, int(bool(diff)), dtype_code(qk), _stream()),
                    'istvt_attn_temporal_fwd')
     return out
 
 
-def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: int, heads: int, dh: int):
+def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: int, heads: int, dh: int, diff: bool = False,
+                      packed: bool = False):
+    """-> (dqk, dv) laid out like qk and v.  packed=True (qk and v are the column ranges [0, 2*inner) and [2*inner,
+    3*inner) of one projection buffer): the two gradients are the same column ranges of ONE [B*F*P, 3*inner] buffer,
+    returned as (dqkv, None) -- the operand of a single input-gradient GEMM."""
     inner = heads * dh
     (qk, ldqk), (v, ldv) = rows(_req(qk)), rows(_req(v))
-    dout, ldd = rows(_req(dout))
-    if ldd != ldv:                       # the kernels take one stride for v, dout and dv
-        d2 = _same_rows(v, ldv, B * F * P, inner)
-        d2.copy_(dout)
-        dout = d2
-    dqk = _same_rows(qk, ldqk, B * F * P, 2 * inner)
-    dv = _same_rows(v, ldv, B * F * P, inner)
-    with prof('attn_temporal_bwd', 7 * B * F * P * heads * dh * qk.element_size(), 10.0 * B * P * heads * F * F * dh):
-        _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), ldqk, v.data_ptr(), dout.data_ptr(),
-                                                      dqk.data_ptr(), dv.data_ptr(), ldv, B, F, P, heads, dh, dh ** -0.5,
-                                                      dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
-    return dqk, dv
+    dout, ldo = rows(_req(dout))
+    M = B * F * P
+    if packed:
+        if ldqk != ldv or v.data_ptr() != qk.data_ptr() + 2 * inner * qk.element_size():
+            raise RuntimeError('attn_temporal_bwd(packed=True): v is not the third column range of the qk buffer')
+        dqkv = _same_rows(qk, ldqk, M, 3 * inner)
+        dqk, dv = dqkv[:, :2 * inner], dqkv[:, 2 * inner:]
+    else:
+        dqkv = None
+        dqk = _same_rows(qk, ldqk, M, 2 * inner)
+        dv = _same_rows(v, ldv, M, inner)
+    with prof('attn_temporal_bwd', 7 * M * inner * qk.element_size(), 10.0 * B * P * heads * F * F * dh):
+        _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), ldqk, v.data_ptr(), ldv, dout.data_ptr(), ldo,
+                                                      dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
+                                                      int(bool(diff)), dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
+    return (dqkv, None) if packed else (dqk, dv)
 
 
 # ------------------------------------------------------------------------------------------

@@ -114,7 +114,7 @@ class GradBucket:
                                    'all_reduce() (call disable_early_all_reduce() for gradient accumulation)')
             if device.type == 'cuda':
                 Fn.join_side_stream(device.index)       # the side-stream weight gradients are part of the slice
-            me._early_work = dist.all_reduce(me.flat[lo:me.numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            me._early_work = (dist.all_reduce(me.flat[lo:me.numel], op=dist.ReduceOp.SUM, group=group, async_op=True), lo)
 
         self._on_ready = on_ready
         Fn.grad_ready_hooks.append(on_ready)
@@ -138,17 +138,27 @@ class GradBucket:
         else:
             self.flat.mul_(1.0 / world)
 
+    def apply_deferred_scale(self):
+        """multiply the bucket by the pending 1 / world-size factor now (one pass) instead of inside the next fused
+        optimizer step: afterwards ``p.grad`` are the global-batch mean gradients, as after a plain all-reduce"""
+        if self.grad_scale != 1.0:
+            self.flat.mul_(self.grad_scale)
+            self.grad_scale = 1.0
+
     def all_reduce(self, group=None, chunks: int = 1):
-        """sum over ranks then divide by world size (== DataParallel's global-batch mean).  With a fused optimizer
-        attached (``defer_scale``) the division happens inside its step kernel."""
+        """sum over ranks then divide by world size (== DataParallel's global-batch mean).
+
+        With a fused optimizer attached (``defer_scale``) the division happens inside its step kernel: between this call
+        and ``optimizer.step()`` every ``p.grad`` holds the cross-rank SUM (``world`` times the mean).  Code that reads
+        gradients in between -- ``clip_grad_norm_``, gradient-norm logging, a non-fused optimizer over ``bucket.params``
+        -- must call ``apply_deferred_scale()`` first."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
         if world == 1:
             return
-        work = self._early_work
-        if work is not None:                # the transformer's slice is already in flight (enable_early_all_reduce)
-            lo = self._early[0]
+        if self._early_work is not None:    # the transformer's slice is already in flight (enable_early_all_reduce)
+            work, lo = self._early_work     # (lo travels with the work: disable_early_all_reduce() may have run since)
             self._early_work = None
             if lo > 0:
                 dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM, group=group)
@@ -225,15 +235,52 @@ class _FusedOptimizer(torch.optim.Optimizer):
         self.bucket.grad_scale = 1.0
         ops.invalidate_weight_cache()       # the kernel wrote parameters without bumping their version counters
 
+    def _slices(self):
+        off = 0
+        for i, p in enumerate(self.bucket.params):
+            n = p.numel()
+            yield i, p, off, n
+            off += n
+
+    def _extra_state(self, i) -> dict:      # per-parameter entries beside the flat buffers (AdamW's step count)
+        return {}
+
     def state_dict(self):
-        return {'steps': self.steps, 'param_groups': [{k: v for k, v in self.hyper.items() if k != 'params'}],
-                'flat_state': {n: getattr(self, n).detach().clone() for n in self._state_names}}
+        """torch.optim's format -- ``{'state': {index: {name: tensor}}, 'param_groups': [{..., 'params': [indices]}]}``
+        -- with the per-parameter tensors cut out of the flat state buffers, so a checkpoint written here loads into
+        torch.optim.SGD / AdamW over the same parameters and the other way round.  ``fused_steps`` (ignored by torch)
+        keeps the step count for SGD, whose torch state has none."""
+        state = {}
+        if self.steps > 0:                  # torch optimizers have no state before their first step either
+            for i, p, off, n in self._slices():
+                st = {name: getattr(self, name)[off:off + n].view_as(p).detach().clone() for name in self._state_names}
+                st.update(self._extra_state(i))
+                state[i] = st
+        group = {k: v for k, v in self.hyper.items() if k != 'params'}
+        group['params'] = list(range(len(self.bucket.params)))
+        return {'state': state, 'param_groups': [group], 'fused_steps': self.steps}
 
     def load_state_dict(self, sd):
-        self.steps = int(sd['steps'])
-        self.hyper.update(sd['param_groups'][0])
-        for n in self._state_names:
-            getattr(self, n).copy_(sd['flat_state'][n])
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.bucket.params):
+            raise ValueError('fused optimizer: expected ONE param group over %d parameters' % len(self.bucket.params))
+        self.hyper.update({k: v for k, v in groups[0].items() if k != 'params' and k in self.hyper})
+        state = sd['state']
+        steps = 0
+        for i, p, off, n in self._slices():
+            st = state.get(i, state.get(str(i)))
+            for name in self._state_names:
+                dst = getattr(self, name)[off:off + n]
+                src = None if st is None else st.get(name)
+                if src is None:
+                    dst.zero_()
+                else:
+                    if src.numel() != n:
+                        raise ValueError('optimizer state %r of parameter %d has %d elements, expected %d' % (name, i, src.numel(), n))
+                    dst.copy_(src.reshape(-1))
+            if st is not None:
+                steps = max(steps, int(float(st['step'])) if 'step' in st else 1)
+        self.steps = int(sd.get('fused_steps', steps))
 
 
 class FusedSGD(_FusedOptimizer):
@@ -248,8 +295,6 @@ class FusedSGD(_FusedOptimizer):
         super().__init__(bucket, dict(lr=float(lr), momentum=float(momentum), dampening=float(dampening),
                                       weight_decay=float(weight_decay), nesterov=bool(nesterov)), zero_grad)
         self.momentum_buffer = torch.zeros_like(bucket.flat)
-
-    lr = property(lambda self: self.hyper['lr'])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -266,6 +311,9 @@ class FusedAdamW(_FusedOptimizer):
     """torch.optim.AdamW(params, lr, betas, eps, weight_decay) (amsgrad off) over the flat buffers."""
 
     _state_names = ('exp_avg', 'exp_avg_sq')
+
+    def _extra_state(self, i):
+        return {'step': torch.tensor(float(self.steps))}
 
     def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2, zero_grad: bool = False):

@@ -161,13 +161,16 @@ class RepChainFn(Function):
         else:
             out = bn_apply(X, in_bn, M, cout, False)
         ctx.sv = dict(spec=spec, Fr=Fr, H=H, W=W, units=units, sk=sk, amax=amax, inp=inp, params=params, training=training)
-        ctx.need_dx = inp.requires_grad
+        ctx.need_dx = ctx.needs_input_grad[0]       # (not inp.requires_grad: a contiguous copy made in here never requires grad)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         sv = ctx.sv
+        if sv is None:
+            raise RuntimeError('RepChainFn: the saved activations were released by the first backward pass '
+                               '(retain_graph=True is not supported for Xception blocks)')
         spec, Fr, H, W, units, sk, params, training = (sv[k] for k in ('spec', 'Fr', 'H', 'W', 'units', 'sk', 'params', 'training'))
         L = _lib.lib()
         dout = _c(dout)

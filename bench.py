@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the ISTVT hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]       (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     (the same ranks, started by the caller)
 
 Workload (BASELINE.json configs[1], "C2"): per GPU B=32 clips x T=8 frames x 3x224x224, full
 ISTVT (Xception stem + 12-layer decomposed spatial-temporal transformer), bf16 activation
@@ -65,7 +65,63 @@ def parse():
                     help='skip the extra K steps that fill the with_dead_row_elimination field (profiled runs: one kind of step in the trace)')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
+    ap.add_argument('--plumbing-only', action='store_true',
+                    help='exercise only the launch / process-group / timing / JSON plumbing (no model, no GPU needed): '
+                         'what the CPU test of the self-launching --gpus N path runs')
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks ourselves, exactly as
+    the documented launch line does, and hand back rank 0's JSON line and the job's exit code.  The parent never
+    touches the GPU (nothing above this call initialises HIP; torch.cuda.device_count() does not either) and does not
+    exec: the ranks are child processes with inherited stdout / stderr.  The reference's own multi-device mode needs
+    no launcher (nn.DataParallel, train_CNN.py:185-186); this keeps `--gpus N` as easy to start."""
+    import socket
+    import subprocess
+    rehearsal = bool(os.environ.get('ISTVT_BENCH_REHEARSAL')) or a.plumbing_only
+    if not rehearsal:
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (a.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    env['MASTER_ADDR'] = '127.0.0.1'
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(a, world, rank):
+    """--plumbing-only: the rank / barrier / max-over-ranks / one-JSON-line skeleton of main() around an empty step, on
+    gloo and the CPU (tests/test_host_cpu.py).  Says so in the line: it measures nothing."""
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    t0 = time.perf_counter()
+    for _ in range(a.warmup + a.steps):
+        if world > 1:
+            dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([elapsed], dtype=torch.float64))
+        per_rank = [float(t.item()) for t in allt]
+    if rank == 0:
+        print(json.dumps({'plumbing_only': True, 'metric': 'none (launch plumbing check)', 'value': 0.0, 'unit': 'clips/s',
+                          'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                          'distributed': {'backend': dist.get_backend() if world > 1 else None,
+                                          'ranks': dist.get_world_size() if world > 1 else 1,
+                                          'per_rank_s': [round(t, 4) for t in per_rank]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def cpu_baseline(frames, size, depth, clips=2, reps=3):
@@ -123,9 +179,13 @@ def pmc_summary_path():
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.plumbing_only:
+        return plumbing_only(a, world, rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -138,8 +198,6 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group('nccl', rank=rank, world_size=world)
-    elif a.gpus > 1:
-        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % a.gpus)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank)

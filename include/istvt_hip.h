@@ -77,17 +77,15 @@ int istvt_wgrad_group_splits(int count, const int* N, const int* K, int M);
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
 int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,
                         float* rstd, long M, int D, float eps, int dtype, istvt_stream_t stream);
-/* also writes diff = frame difference of y (module.py:193): rows (b,f,p), diff[f] = y[f] - y[f-1] for f >= 2 */
-int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
-                             void* diff, long ldd, float* mean, float* rstd, int B, int F, int P, int D, float eps,
-                             int dtype, istvt_stream_t stream);
-/* dy2 (may be NULL) = gradient w.r.t. diff; dres (may be NULL) = gradient arriving through the
- * residual connection, added to dx.  dgamma/dbeta accumulate.  dcol (may be NULL) accumulates the column sums of
- * dx: the bias gradient of the nn.Linear whose output this LayerNorm normalises (module.py:30,77,186). */
-int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* dy2, long ld_dy2, const void* x, long ld_x,
-                        const float* mean, const float* rstd, const float* gamma, const void* dres, long ld_res,
-                        void* dx, long ld_dx, float* dgamma, float* dbeta, float* dcol, long M, int D, int F, int P,
-                        int dtype, istvt_stream_t stream);
+/* dres (may be NULL) = gradient arriving through the residual connection, added to dx.  dgamma / dbeta accumulate.
+ * dcol (may be NULL) accumulates the column sums of dx: the bias gradient of the nn.Linear whose output this LayerNorm
+ * normalises (module.py:30,77,186).  ws: float scratch of >= istvt_layernorm_bwd_ws_elems(M, D) elements for the
+ * per-workgroup partial sums; the parameter gradients are reduced in a fixed order (bit-reproducible, no atomics). */
+int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, const float* mean, const float* rstd,
+                        const float* gamma, const void* dres, long ld_res, void* dx, long ld_dx, float* dgamma,
+                        float* dbeta, float* dcol, float* ws, long ws_elems, long M, int D, int dtype,
+                        istvt_stream_t stream);
+int istvt_layernorm_bwd_ws_elems(long M, int D);
 
 /* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
  * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)') with row stride ldqkv (elements; also dqkv's), out / dout
@@ -108,13 +106,19 @@ int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const void* out, con
                                float* delta, void* dqkv, int BF, int P, int heads, int dh, float scale, int dtype,
                                istvt_stream_t stream);
 
-/* ---- temporal attention (TemporalResidualAttention.forward core, module.py:197-205) --------
- * qk [B*F*P][2*heads*dh] (q|k) with row stride ldqk (also dqk's); v / out / dout / dv [B*F*P][heads*dh] with row
- * stride ldv; rows (b,f,p); F <= 17 (float32), <= 32 (bfloat16). */
-int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, void* out, long ldv, int B, int F, int P, int heads,
-                            int dh, float scale, int dtype, istvt_stream_t stream);
-int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, const void* dout, void* dqk, void* dv, long ldv,
-                            int B, int F, int P, int heads, int dh, float scale, int dtype, istvt_stream_t stream);
+/* ---- temporal attention (TemporalResidualAttention.forward core, module.py:192-205) --------
+ * qk [B*F*P][2*heads*dh] (q|k) with row stride ldqk (also dqk's); v / dv [B*F*P][heads*dh] with row stride ldv;
+ * out / dout [B*F*P][heads*dh] with row stride ldo; rows (b,f,p); F <= 17 (float32), <= 32 (bfloat16).
+ * qk and v may be column ranges of ONE [B*F*P][3*heads*dh] projection (v = qk + 2*heads*dh, ldv = ldqk).
+ * diff != 0: q and k are the projections of the UN-differenced LayerNorm output; the kernels take the frame
+ * difference of module.py:193 on them (q'[f] = q[f] - q[f-1] for f >= 2; exact because to_qk has no bias,
+ * module.py:182) and the backward returns gradients with respect to the un-differenced rows.  diff == 0: plain
+ * attention over frames (TemporalOnlyAttention, module.py:145-172). */
+int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, long ldv, void* out, long ldo, int B, int F, int P,
+                            int heads, int dh, float scale, int diff, int dtype, istvt_stream_t stream);
+int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, long ldv, const void* dout, long ldo, void* dqk,
+                            void* dv, int B, int F, int P, int heads, int dh, float scale, int diff, int dtype,
+                            istvt_stream_t stream);
 
 /* ---- token assembly (DSTTr.forward, vivit.py:133-142) -------------------------------------- */
 int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, long ldx,

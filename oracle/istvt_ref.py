@@ -360,6 +360,47 @@ def xception_logits(p: Params, feats: Tensor, head: str = 'last_linear') -> Tens
     return F.linear(x, p[head + '.weight'], p[head + '.bias'])
 
 
+# ---- DualNet's Xception halves (network/xception_for_dualnet.py:215-284; consumed at dual_net.py:210-232) ----
+def _xception_entry(p: Params, x: Tensor, training: bool) -> Tensor:
+    x = F.relu(_bn(p, 'bn1', F.conv2d(x, p['conv1.weight'], None, 2, 0), training))
+    return F.relu(_bn(p, 'bn2', F.conv2d(x, p['conv2.weight']), training))
+
+
+def _xception_blocks(p: Params, x: Tensor, first: int, last: int, training: bool) -> Tensor:
+    for name, cin, cout, reps, strides, relu0, grow in XCEPTION_BLOCKS[first - 1:last]:
+        x = block_forward(p, name, x, cin, cout, reps, strides, relu0, grow, training)
+    return x
+
+
+def _xception_exit(p: Params, x: Tensor, training: bool) -> Tensor:
+    x = F.relu(_bn(p, 'bn3', _sepconv(p, 'conv3', x), training))
+    return _bn(p, 'bn4', _sepconv(p, 'conv4', x), training)
+
+
+def xception_fea(p: Params, which: str, x: Tensor, training: bool = True) -> Tensor:
+    """The partial forwards of xception_for_dualnet.Xception: 'fea_0_7' (conv1 .. block7, :215-231), 'fea_8_12' (block8
+    .. bn4, :233-246), 'fea_0_4' (:248-262), 'fea_5_8' (:264-270), 'fea_9_12' (:272-284).  Same layers and state-dict
+    names as network/xception.py's Xception; the exit flow ends at bn4 with no ReLU."""
+    if which == 'fea_0_7':
+        return _xception_blocks(p, _xception_entry(p, x, training), 1, 7, training)
+    if which == 'fea_0_4':
+        return _xception_blocks(p, _xception_entry(p, x, training), 1, 4, training)
+    if which == 'fea_5_8':
+        return _xception_blocks(p, x, 5, 8, training)
+    if which == 'fea_8_12':
+        return _xception_exit(p, _xception_blocks(p, x, 8, 12, training), training)
+    if which == 'fea_9_12':
+        return _xception_exit(p, _xception_blocks(p, x, 9, 12, training), training)
+    raise ValueError(which)
+
+
+def xception_dualnet_logits(p: Params, feats: Tensor, head: str = 'last_linear'):
+    """xception_for_dualnet.Xception.logits (:317-324) in eval mode (dp is then the identity): (pooled features, head
+    output)."""
+    y = F.adaptive_avg_pool2d(F.relu(feats), (1, 1)).flatten(1)
+    return y, F.linear(y, p[head + '.weight'], p[head + '.bias'])
+
+
 def xception_param_shapes(num_classes: int = 1000) -> Dict[str, tuple]:
     s: Dict[str, tuple] = {}
 

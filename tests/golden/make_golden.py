@@ -448,8 +448,74 @@ def g8_siblings():
     save('G8_siblings', **out)
 
 
+def g9_dualnet_halves():
+    """DualNet's Xception halves (xception_for_dualnet.py:215-284, the split points dual_net.py:210-232 calls): fea_0_7,
+    fea_8_12, fea_0_4, fea_5_8, fea_9_12 of the reference's own class at 171^2, batch 2, train mode, float32 + float64;
+    eval-mode forward() -> (pooled features, logits) with the classifier renamed as get_xception does (:349-351)."""
+    import network.xception_for_dualnet as ref_xd
+    out = {}
+    shape = (2, 3, 171, 171)
+    for dtype, tag in ((torch.float32, ''), (torch.float64, 'f64.')):
+        f64 = dtype == torch.float64
+        net = ref_xd.Xception(num_classes=1)
+        load_rand(net, 'g9.net.')
+        net = net.to(dtype).train()
+        x = t(recipe.rand_input_value('g9.net.x', shape)).to(dtype).requires_grad_(True)
+        a = net.fea_0_7(x)                                  # (2, 728, 11, 11)
+        b = net.fea_8_12(a)                                 # (2, 2048, 6, 6)
+        coef = t(recipe.rand_input_value('g9.net.coef', tuple(b.shape))).to(dtype)
+        (b * coef).sum().backward()
+        out[tag + 'fea_0_7_sub'] = npy(a[:, ::8])
+        out[tag + 'fea_8_12_sub'] = npy(b[:, ::16])
+        out[tag + 'dx_norm'] = npy(x.grad.norm())
+        for k, p_ in net.named_parameters():
+            if p_.grad is not None:
+                out[tag + 'gnorm.' + k] = npy(p_.grad.norm())
+        if not f64:
+            sd = net.state_dict()
+            for k in ('bn2', 'block7.rep.8', 'block8.rep.2', 'block12.skipbn', 'bn4'):
+                out['buf.' + k + '.running_mean'] = npy(sd[k + '.running_mean'])
+                out['buf.' + k + '.running_var'] = npy(sd[k + '.running_var'])
+        # the three-way split on a fresh copy (fresh running statistics): same layers, same result
+        net3 = ref_xd.Xception(num_classes=1)
+        load_rand(net3, 'g9.net.')
+        net3 = net3.to(dtype).train()
+        with torch.no_grad():
+            c4 = net3.fea_0_4(t(recipe.rand_input_value('g9.net.x', shape)).to(dtype))
+            c8 = net3.fea_5_8(c4)
+            c12 = net3.fea_9_12(c8)
+        out[tag + 'fea_0_4_sub'] = npy(c4[:, ::8])
+        out[tag + 'fea_5_8_sub'] = npy(c8[:, ::8])
+        out[tag + 'fea_9_12_sub'] = npy(c12[:, ::16])
+        # a middle piece by itself with its own input and gradient (what dual_net.py:221-222 does with the fused features)
+        net5 = ref_xd.Xception(num_classes=1)
+        load_rand(net5, 'g9.net.')
+        net5 = net5.to(dtype).train()
+        xm = t(recipe.rand_input_value('g9.mid.x', (2, 728, 11, 11))).to(dtype).requires_grad_(True)
+        ym = net5.fea_8_12(xm)
+        cm = t(recipe.rand_input_value('g9.mid.coef', tuple(ym.shape))).to(dtype)
+        (ym * cm).sum().backward()
+        out[tag + 'mid.fea_8_12_sub'] = npy(ym[:, ::16])
+        out[tag + 'mid.dx_norm'] = npy(xm.grad.norm())
+        if not f64:
+            out['mid.dx'] = npy(xm.grad[:, ::8])
+        for k in ('block8.rep.1.conv1.weight', 'block11.rep.7.pointwise.weight', 'block12.skip.weight', 'conv4.pointwise.weight', 'bn4.weight'):
+            out[tag + 'mid.gnorm.' + k] = npy(dict(net5.named_parameters())[k].grad.norm())
+    # eval-mode forward: (y, x) = (pooled features, last_linear(dp(y))), fc renamed as get_xception does
+    net = ref_xd.Xception(num_classes=1)
+    load_rand(net, 'g9.net.')
+    net.last_linear = net.fc
+    del net.fc
+    net.eval()
+    with torch.no_grad():
+        y, lg = net(t(recipe.rand_input_value('g9.net.x', shape)))
+    out['eval.pooled_sub'] = npy(y[:, ::16])
+    out['eval.logits'] = npy(lg)
+    save('G9_dualnet_halves', **out)
+
+
 ALL.update({'G1b': g1b_stem224, 'G2b': g2b_modules_f17, 'G4b': g4b_dsttr_t16, 'G5b': g5b_native_fp64, 'G7': g7_xception,
-            'G8': g8_siblings})
+            'G8': g8_siblings, 'G9': g9_dualnet_halves})
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

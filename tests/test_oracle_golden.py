@@ -298,6 +298,69 @@ def test_g7_xception_eval(golden_dir):
     assert relerr(logits, g['net.eval.logits']) < 1e-4
 
 
+def _g9_shapes():
+    s = R.xception_param_shapes(1)
+    s['fc.weight'] = s.pop('last_linear.weight')          # xception_for_dualnet.Xception keeps `fc` until get_xception renames it
+    s['fc.bias'] = s.pop('last_linear.bias')
+    return s
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_g9_dualnet_halves(golden_dir, dtype):
+    """DualNet's Xception halves (xception_for_dualnet.py:215-284): fea_8_12(fea_0_7(x)) forward + backward, the
+    three-way split fea_9_12(fea_5_8(fea_0_4(x))), and fea_8_12 by itself on a feature-shaped input."""
+    g = load(golden_dir, 'G9_dualnet_halves')
+    f64 = dtype == torch.float64
+    tag = 'f64.' if f64 else ''
+    tf, tg = (1e-9, 1e-8) if f64 else (1e-4, 5e-3)
+    p = R.with_grad(rand_params(_g9_shapes(), 'g9.net.', dtype))
+    x = torch.from_numpy(recipe.rand_input_value('g9.net.x', (2, 3, 171, 171))).to(dtype).requires_grad_(True)
+    a = R.xception_fea(p, 'fea_0_7', x)
+    b = R.xception_fea(p, 'fea_8_12', a)
+    coef = torch.from_numpy(recipe.rand_input_value('g9.net.coef', tuple(b.shape))).to(dtype)
+    (b * coef).sum().backward()
+    assert relerr(a.detach()[:, ::8], g[tag + 'fea_0_7_sub']) < tf
+    assert relerr(b.detach()[:, ::16], g[tag + 'fea_8_12_sub']) < tf
+    assert relerr(x.grad.norm(), g[tag + 'dx_norm']) < tg
+    worst = max((relerr(v.grad.norm(), g[tag + 'gnorm.' + k]), k) for k, v in p.items() if v.requires_grad and v.grad is not None)
+    assert worst[0] < tg, worst
+    if not f64:
+        for k in ('bn2', 'block7.rep.8', 'block8.rep.2', 'block12.skipbn', 'bn4'):
+            assert relerr(p[k + '.running_var'], g['buf.' + k + '.running_var']) < 1e-4, k
+            assert relerr(p[k + '.running_mean'], g['buf.' + k + '.running_mean']) < 1e-4, k
+    p3 = rand_params(_g9_shapes(), 'g9.net.', dtype)
+    with torch.no_grad():
+        c4 = R.xception_fea(p3, 'fea_0_4', x.detach())
+        c8 = R.xception_fea(p3, 'fea_5_8', c4)
+        c12 = R.xception_fea(p3, 'fea_9_12', c8)
+    assert relerr(c4[:, ::8], g[tag + 'fea_0_4_sub']) < tf
+    assert relerr(c8[:, ::8], g[tag + 'fea_5_8_sub']) < tf
+    assert relerr(c12[:, ::16], g[tag + 'fea_9_12_sub']) < tf
+    p5 = R.with_grad(rand_params(_g9_shapes(), 'g9.net.', dtype))
+    xm = torch.from_numpy(recipe.rand_input_value('g9.mid.x', (2, 728, 11, 11))).to(dtype).requires_grad_(True)
+    ym = R.xception_fea(p5, 'fea_8_12', xm)
+    cm = torch.from_numpy(recipe.rand_input_value('g9.mid.coef', tuple(ym.shape))).to(dtype)
+    (ym * cm).sum().backward()
+    assert relerr(ym.detach()[:, ::16], g[tag + 'mid.fea_8_12_sub']) < tf
+    assert relerr(xm.grad.norm(), g[tag + 'mid.dx_norm']) < tg
+    if not f64:
+        assert relerr(xm.grad[:, ::8], g['mid.dx']) < tg
+    for k in ('block8.rep.1.conv1.weight', 'block11.rep.7.pointwise.weight', 'block12.skip.weight', 'conv4.pointwise.weight', 'bn4.weight'):
+        assert relerr(p5[k].grad.norm(), g[tag + 'mid.gnorm.' + k]) < tg, k
+
+
+def test_g9_dualnet_eval(golden_dir):
+    g = load(golden_dir, 'G9_dualnet_halves')
+    s = _g9_shapes()
+    p = rand_params(s, 'g9.net.')
+    x = torch.from_numpy(recipe.rand_input_value('g9.net.x', (2, 3, 171, 171)))
+    with torch.no_grad():
+        feats = R.xception_fea(p, 'fea_8_12', R.xception_fea(p, 'fea_0_7', x, training=False), training=False)
+        y, lg = R.xception_dualnet_logits(p, feats, head='fc')
+    assert relerr(y[:, ::16], g['eval.pooled_sub']) < 1e-4
+    assert relerr(lg, g['eval.logits']) < 1e-4
+
+
 def _vit_shapes(dim, depth, heads, dh, mlp, prefix):
     inner = heads * dh
     s = {}

@@ -191,3 +191,73 @@ def test_eval_mode_stem_backward_matches_oracle():
     worst = max((relerr(named[k].grad, pr[k].grad), k) for k in S.param_names())
     assert worst[0] < 2e-3, worst
     assert relerr(net.state_dict()['bn1.running_mean'], p['bn1.running_mean']) == 0.0
+
+
+def test_g9_dualnet_xception_halves_hip(golden_dir):
+    """SURVEY 8(f) row 3, second half: the Xception of the reference's DualNet (network/xception_for_dualnet.py:215-284;
+    called at dual_net.py:210-232) on the HIP block chain against golden G9 captured from the reference class:
+    fea_8_12(fea_0_7(x)) forward + backward, the three-way split fea_9_12(fea_5_8(fea_0_4(x))), fea_8_12 by itself on a
+    feature-shaped input, and the eval-mode forward() -> (pooled features, logits)."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network import xception_for_dualnet as XD
+    g = np.load(os.path.join(golden_dir, 'G9_dualnet_halves.npz'))
+    shape = (2, 3, 171, 171)
+    net = load_rand(XD.Xception(num_classes=1), 'g9.net.')
+    x = torch.from_numpy(recipe.rand_input_value('g9.net.x', shape)).cuda().requires_grad_(True)
+    a = net.fea_0_7(x)
+    assert tuple(a.shape) == (2, 728, 11, 11)
+    b = net.fea_8_12(a)
+    assert tuple(b.shape) == (2, 2048, 6, 6)
+    coef = torch.from_numpy(recipe.rand_input_value('g9.net.coef', tuple(b.shape))).cuda()
+    (b * coef).sum().backward()
+    assert relerr(a[:, ::8], g['fea_0_7_sub']) < 1e-3
+    assert relerr(b[:, ::16], g['fea_8_12_sub']) < 1e-3
+    rows = []
+    for k, p in net.named_parameters():
+        if ('gnorm.' + k) not in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k        # fc: not on the path
+            continue
+        r32, r64 = float(g['gnorm.' + k]), float(g['f64.gnorm.' + k])
+        rows.append((abs(float(p.grad.norm()) - r64) / max(3.0 * abs(r32 - r64) + 2e-3 * abs(r64), 1e-30), k,
+                     float(p.grad.norm()), r32, r64))
+    rows.sort(reverse=True)
+    print('G9 worst gradient-norm ratios:', rows[:5])
+    assert rows[0][0] <= 1.0, rows[:5]
+    assert within_ref_spread(x.grad.norm(), g['dx_norm'], g['f64.dx_norm'], floor=2e-3)
+    sd = net.state_dict()
+    for k in ('bn2', 'block7.rep.8', 'block8.rep.2', 'block12.skipbn', 'bn4'):
+        assert relerr(sd[k + '.running_var'], g['buf.' + k + '.running_var']) < 1e-3, k
+        assert relerr(sd[k + '.running_mean'], g['buf.' + k + '.running_mean']) < 5e-3, k
+    # the three-way split on fresh statistics
+    net3 = load_rand(XD.Xception(num_classes=1), 'g9.net.')
+    with torch.no_grad():
+        c4 = net3.fea_0_4(x.detach())
+        c8 = net3.fea_5_8(c4)
+        c12 = net3.fea_9_12(c8)
+    assert relerr(c4[:, ::8], g['fea_0_4_sub']) < 1e-3
+    assert relerr(c8[:, ::8], g['fea_5_8_sub']) < 1e-3
+    assert relerr(c12[:, ::16], g['fea_9_12_sub']) < 1e-3
+    # fea_8_12 on a plain NCHW feature tensor (what DualNet feeds it after its fusion convolution), with gradients
+    net5 = load_rand(XD.Xception(num_classes=1), 'g9.net.')
+    xm = torch.from_numpy(recipe.rand_input_value('g9.mid.x', (2, 728, 11, 11))).cuda().requires_grad_(True)
+    ym = net5.fea_8_12(xm)
+    cm = torch.from_numpy(recipe.rand_input_value('g9.mid.coef', tuple(ym.shape))).cuda()
+    (ym * cm).sum().backward()
+    assert relerr(ym[:, ::16], g['mid.fea_8_12_sub']) < 1e-3
+    assert relerr(xm.grad[:, ::8], g['mid.dx']) < 2e-3
+    assert within_ref_spread(xm.grad.norm(), g['mid.dx_norm'], g['f64.mid.dx_norm'], floor=2e-3)
+    named = dict(net5.named_parameters())
+    for k in ('block8.rep.1.conv1.weight', 'block11.rep.7.pointwise.weight', 'block12.skip.weight', 'conv4.pointwise.weight', 'bn4.weight'):
+        assert within_ref_spread(named[k].grad.norm(), g['mid.gnorm.' + k], g['f64.mid.gnorm.' + k], floor=2e-3), k
+    # eval-mode forward of the get_xception() form: fc renamed to last_linear, (pooled, logits) pair
+    ev = XD.get_xception(1)
+    sd = ev.state_dict()
+    ev.load_state_dict({k: torch.from_numpy(recipe.rand_param_value('g9.net.' + k.replace('last_linear', 'fc'), tuple(v.shape)))
+                        for k, v in sd.items()})
+    ev = ev.cuda().eval()
+    with torch.no_grad():
+        y, lg = ev(x.detach())
+    assert tuple(y.shape) == (2, 2048) and tuple(lg.shape) == (2, 1)
+    assert relerr(y[:, ::16], g['eval.pooled_sub']) < 1e-3
+    assert relerr(lg, g['eval.logits']) < 1e-3

@@ -33,15 +33,14 @@ def rnd(*s):
 
 x, dy, dy2, dres = rnd(M, D), rnd(M, D), rnd(M, D), rnd(M, D)
 g, b = torch.randn(D, device='cuda'), torch.randn(D, device='cuda')
-dg, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+dg, db, dc = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
 y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
 row = M * D * 2
 for name, fn, nbytes in [
     ('ln_fwd', lambda: ops.layernorm_fwd(x, g, b, 1e-5), 2 * row),
-    ('ln_fwd_diff', lambda: ops.layernorm_fwd_diff(x, g, b, 1e-5, B, F, P), 3 * row),
     ('ln_bwd', lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db), 3 * row),
     ('ln_bwd + dres', lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres), 4 * row),
-    ('ln_bwd temporal + dres', lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dy2=dy2, dres=dres, F=F, P=P), 5 * row),
+    ('ln_bwd + dres + dcol', lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres, dcol=dc), 4 * row),
     ('colsum', lambda: ops.colsum(dy, db), row),
 ]:
     t = timeit(fn)

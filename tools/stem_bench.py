@@ -50,7 +50,5 @@ t = timeit(lambda: ops.layernorm_bwd(x, x, mean, rstd, g, dg, db))
 print('layernorm bwd   %7.1f us  %6.0f GB/s' % (t * 1e6, 3 * M * D * 2 / t / 1e9))
 t = timeit(lambda: ops.layernorm_bwd(x, x, mean, rstd, g, dg, db, dres=x))
 print('layernorm bwd+r %7.1f us  %6.0f GB/s' % (t * 1e6, 4 * M * D * 2 / t / 1e9))
-t = timeit(lambda: ops.layernorm_fwd_diff(x, g, b, 1e-5, 32, 9, 197))
-print('layernorm diff  %7.1f us  %6.0f GB/s' % (t * 1e6, 3 * M * D * 2 / t / 1e9))
 t = timeit(lambda: ops.colsum(x))
 print('colsum          %7.1f us  %6.0f GB/s' % (t * 1e6, M * D * 2 / t / 1e9))

@@ -27,10 +27,13 @@ def timeit(fn, reps=10):
 
 for F in (9, 17):
     M = B * F * P
-    qk = torch.randn(M, 1024, device='cuda').to(dt)
-    v = torch.randn(M, 512, device='cuda').to(dt)
-    do = torch.randn(M, 512, device='cuda').to(dt)
-    t = timeit(lambda: ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh))
+    # the model's form: one packed, line-aligned q|k|v projection, frame difference in the kernels, packed gradient
+    qkv = ops.empty_rows(M, 1536, dt, 'cuda')
+    qkv.copy_(torch.randn(M, 1536, device='cuda'))
+    qk, v = qkv[:, :1024], qkv[:, 1024:]
+    do = ops.empty_rows(M, 512, dt, 'cuda')
+    do.copy_(torch.randn(M, 512, device='cuda'))
+    t = timeit(lambda: ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh, diff=True))
     print('F=%2d fwd %7.1f us  %5.2f TB/s' % (F, t * 1e6, M * 2048 * 2 / t / 1e12), flush=True)
-    t = timeit(lambda: ops.attn_temporal_bwd(qk, v, do, B, F, P, heads, dh))
+    t = timeit(lambda: ops.attn_temporal_bwd(qk, v, do, B, F, P, heads, dh, diff=True, packed=True))
     print('F=%2d bwd %7.1f us  %5.2f TB/s' % (F, t * 1e6, M * 3584 * 2 / t / 1e12), flush=True)
