@@ -26,7 +26,7 @@ SIGNATURES = {
     'istvt_attn_temporal_fwd': [P, L, P, L, P, L, I, I, I, I, I, F, I, I, P],
     'istvt_attn_temporal_bwd': [P, L, P, L, P, L, P, P, I, I, I, I, I, F, I, I, P],
     'istvt_tokens_fwd': [P, P, P, P, P, L, I, I, I, I, I, I, P],
-    'istvt_tokens_bwd': [P, L, P, P, P, P, I, I, I, I, I, I, P],
+    'istvt_tokens_bwd': [P, L, P, P, P, P, P, I, I, I, I, I, I, P],
     'istvt_frame_diff': [P, P, I, I, I, I, I, I, P],
     'istvt_stats_replicas': [],
     'istvt_stats_reduce': [P, I, P],
@@ -49,21 +49,24 @@ SIGNATURES = {
     'istvt_im2col3x3': [P, P, I, P, I, I, I, I, I, P],
     'istvt_col2im3x3': [P, P, P, P, I, I, I, I, I, P],
     'istvt_dwconv3x3': [P, P, P, I, I, I, I, P, I, I, P, P, I, I, P, I, I, P, P, I, P],
-    'istvt_dwconv3x3_wgrad': [P, P, I, P, P, I, I, I, I, I, P],
+    'istvt_dwconv3x3_wgrad': [P, P, I, P, P, P, L, I, I, I, I, I, P],
+    'istvt_dwconv3x3_wgrad_ws_elems': [I, I, I, I],
     'istvt_pool_add_fwd': [P, P, P, P, P, P, I, I, I, I, I, P],
     'istvt_pool_bwd': [P, P, P, I, I, I, I, P, P, P, P, I, P],
     'istvt_subsample2': [P, P, I, I, I, I, I, P],
     'istvt_splitk_reduce': [P, I, L, P, P],
     'istvt_wgrad_group': [I, P, P, P, P, P, P, P, I, I, P, L, P],
     'istvt_wgrad_group_splits': [I, P, P, I],
-    'istvt_colsum': [P, P, L, I, L, I, P],
+    'istvt_colsum': [P, P, L, I, L, P, L, I, P],
+    'istvt_colsum_ws_elems': [L, I],
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
     'istvt_cast_transpose': [P, L, P, L, P, L, I, I, P],
     'istvt_relu_avgpool_fwd': [P, P, I, I, I, I, I, P],
     'istvt_relu_avgpool_bwd': [P, P, P, I, I, I, I, I, P],
     'istvt_prepend_fwd': [P, P, P, P, L, L, I, I, I, I, I, P],
-    'istvt_prepend_bwd': [P, L, P, P, P, L, I, I, I, I, I, P],
+    'istvt_prepend_bwd': [P, L, P, P, P, P, L, I, I, I, I, I, P],
+    'istvt_prepend_bwd_ws_rows': [L, I, I],
     'istvt_seq_mean_fwd': [P, L, P, L, I, I, I, P],
     'istvt_seq_mean_bwd': [P, P, L, L, I, I, I, P],
     'istvt_dropout_fwd': [P, L, P, L, P, L, I, F, ctypes.c_ulonglong, I, P],

@@ -55,6 +55,12 @@ static inline long istvt_tune(const char* name, long dflt) {
 static inline constexpr long istvt_tune(const char*, long dflt) { return dflt; }
 #endif
 
+// Fixed-order column reduction (defined in elementwise.hip), the second stage of every per-column sum that used to end in
+// float atomics: out_a[c] += sum_{r < rows} ws[(r * nacc + a) * N + c] for a < nacc <= 3, rows summed in index order by a
+// single writer per column.  Kernels store one partial row per workgroup into a caller-owned float workspace and this
+// launch folds them: two runs give the same bits, and no workgroup ends in a tail of same-address atomics.
+int istvt_rows_reduce_add(const float* ws, int rows, int nacc, int N, float* o0, float* o1, float* o2, hipStream_t stream);
+
 static inline int istvt_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ISTVT_OK : -(1000 + (int)e);

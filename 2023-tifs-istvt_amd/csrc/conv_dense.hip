@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv2_dgrad_kernel(const bf16_t* __res
 // and every wave owns one 16-channel slice of co: its row operand is the transposed read of dimg (8 consecutive pixels
 // of one channel, ds_read_b64_tr_b16), its column operands the transposed reads of aimg shifted by the tap.
 // 18 accumulator tiles per wave ([tap][2 ci tiles]); at the end each workgroup writes its fp32 partial [64][288] to
-// its slab and slab_reduce_kernel sums the slabs into the gradient.
+// its slab and istvt_rows_reduce_add sums the slabs into the gradient in slab order (no atomics).
 constexpr int WG_PX = 32;
 constexpr int DIMG_PITCH = 64 * 2 + 16;       // bytes per pixel row (+16: the 4 k-rows of one tr read land in 4 bank groups)
 constexpr int AIMG_PITCH = 32 * 2 + 16;
@@ -426,16 +426,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const TD* __restrict__
     for (int i = 0; i < 4; ++i) out[(16 * mt + 4 * g + i) * 32 + 16 * nt + r] = acc[i];
 }
 
-// dw[i] += sum over slabs: blockIdx.y takes every gridDim.y-th slab
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, int n,
-                                                          float* __restrict__ dw) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a = 0.f;
-    for (int sidx = blockIdx.y; sidx < nslabs; sidx += gridDim.y) a += slabs[(long)sidx * n + i];
-    atomicAdd(dw + i, a);
-}
-
 inline int wave_grid(int ngroups, int per_cu) {
     const int need = (ngroups + 3) / 4;
     const int cap = 256 * per_cu;
@@ -498,9 +488,7 @@ extern "C" int istvt_conv2_wgrad(const void* du2, const void* u1, const float* b
     int rc = istvt_check_launch();
     if (rc != ISTVT_OK) return rc;
     const int n = 64 * 288;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((n + 255) / 256, grid < 16 ? grid : 16), dim3(256), 0, stream, slabs,
-                       grid, n, dw);
-    return istvt_check_launch();
+    return istvt_rows_reduce_add(slabs, grid, 1, n, dw, nullptr, nullptr, stream);       // slabs in index order, no atomics
 }
 
 // conv1 weight gradient: du1 [frames*Ho*Wo][32] (dtype), x float [frames][3][S][S] -> dw float [32][32] +=, column
@@ -521,6 +509,5 @@ extern "C" int istvt_conv1_wgrad(const void* du1, const float* x, float* slabs, 
                                              slabs, S, Ho, Ho, (int)nrows));
     int rc = istvt_check_launch();
     if (rc != ISTVT_OK) return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(4, grid < 16 ? grid : 16), dim3(256), 0, stream, slabs, grid, 1024, dw);
-    return istvt_check_launch();
+    return istvt_rows_reduce_add(slabs, grid, 1, 1024, dw, nullptr, nullptr, stream);
 }

@@ -4,10 +4,45 @@
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
-// out[n] += sum_m x[m][n]   (bias gradient of a Linear: colsum of dY).  fp32 accumulate, one
-// atomic per column per block.  Thread owns 8 consecutive columns; 4 waves split the rows.
+// istvt_rows_reduce_add (common.h): one thread per (16-row group, column), a workgroup = 64 columns x 16 row groups; every
+// group sums its rows in index order, the 16 group sums are added in group order by the group-0 thread.
+__global__ __launch_bounds__(1024) void rows_reduce_add_kernel(const float* __restrict__ ws, int rows, int nacc, int N,
+                                                               float* __restrict__ o0, float* __restrict__ o1,
+                                                               float* __restrict__ o2) {
+    __shared__ float part[16][64];
+    const int a = blockIdx.y, cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int per = (rows + 15) / 16, b0 = grp * per, b1 = min(rows, b0 + per);
+    float s = 0.f;
+    if (col < N) {
+        const float* p = ws + (long)a * N + col;
+        const long step = (long)nacc * N;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += p[b * step];
+    }
+    part[grp][cl] = s;
+    __syncthreads();
+    if (grp == 0 && col < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += part[g2][cl];
+        float* out = a == 0 ? o0 : (a == 1 ? o1 : o2);
+        out[col] += t;
+    }
+}
+
+int istvt_rows_reduce_add(const float* ws, int rows, int nacc, int N, float* o0, float* o1, float* o2, hipStream_t stream) {
+    if (rows <= 0 || nacc < 1 || nacc > 3 || N <= 0) return ISTVT_ERR_SHAPE;
+    hipLaunchKernelGGL(rows_reduce_add_kernel, dim3((N + 63) / 64, nacc), dim3(1024), 0, stream, ws, rows, nacc, N, o0, o1, o2);
+    return istvt_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// out[n] += sum_m x[m][n]   (bias gradient of a Linear: colsum of dY).  fp32 accumulate.  Thread owns 8 consecutive
+// columns; 4 waves split the rows of a row block; every row block stores ONE partial row (ws[row block][N]) and
+// istvt_rows_reduce_add folds them in index order.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N,
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ ws, long M, int N,
                                                      long ld, int rows_per_block) {
     __shared__ float red[4][512];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -39,20 +74,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     __syncthreads();
     for (int c = threadIdx.x; c < 512; c += 256) {
         const int gc = blockIdx.x * 512 + c;
-        if (gc < N) atomicAdd(out + gc, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+        if (gc < N) ws[(long)blockIdx.y * N + gc] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
 }
 
-extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, hipStream_t stream) {
-    if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0) return ISTVT_ERR_SHAPE;
-    // 256 row blocks: every block ends with one float atomic per column into the SAME N addresses, and same-address
-    // atomics serialise at the memory side (1024 row blocks were slower than 256 although the loads ran faster)
-    static const long rb = istvt_tune("ISTVT_COLSUM_ROWBLOCKS", 256);
+static int colsum_rows_per_block(long M) {
+    static const long rb = istvt_tune("ISTVT_COLSUM_ROWBLOCKS", 512);
     int rpb = (int)((M + rb - 1) / rb);
-    if (rpb < 64) rpb = 64;
-    dim3 grid((N + 511) / 512, (unsigned)((M + rpb - 1) / rpb)), block(256);
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)x, out, M, N, ld, rpb));
-    return istvt_check_launch();
+    return rpb < 64 ? 64 : rpb;
+}
+// float elements of the workspace istvt_colsum needs for an [M][N] input (one partial row per row block)
+extern "C" int istvt_colsum_ws_elems(long M, int N) {
+    if (M <= 0 || N <= 0) return ISTVT_ERR_SHAPE;
+    const int rpb = colsum_rows_per_block(M);
+    return (int)(((M + rpb - 1) / rpb) * N);
+}
+
+extern "C" int istvt_colsum(const void* x, float* out, long M, int N, long ld, float* ws, long ws_elems, int dtype,
+                            hipStream_t stream) {
+    if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0 || !ws) return ISTVT_ERR_SHAPE;
+    const int rpb = colsum_rows_per_block(M);
+    const int rblocks = (int)((M + rpb - 1) / rpb);
+    if (ws_elems < (long)rblocks * N) return ISTVT_ERR_SHAPE;
+    dim3 grid((N + 511) / 512, (unsigned)rblocks), block(256);
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, stream, (const T*)x, ws, M, N, ld, rpb));
+    int rc = istvt_check_launch();
+    if (rc) return rc;
+    return istvt_rows_reduce_add(ws, rblocks, 1, N, out, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -90,12 +138,12 @@ __global__ __launch_bounds__(128) void tokens_fwd_kernel(const T* __restrict__ f
 
 // backward of the assembly.  grid (P, F); loops over b.
 //   dfeats[b,t,i] = dx[b,1+t,1+i];  dpos[t][p] += sum_b dx[b,1+t,p];
-//   dspace += sum_{b,t} dx[b,1+t,0];  dtemporal += sum_{b,p} dx[b,0,p]
+//   dspace += sum_{b,t} dx[b,1+t,0];  dtemporal += sum_{b,p} dx[b,0,p]   (per-block partial rows + the fixed-order reduce)
 template <typename T>
 __global__ __launch_bounds__(128) void tokens_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dfeats,
-                                                         float* __restrict__ dspace, float* __restrict__ dtemporal,
-                                                         float* __restrict__ dpos, int B, int F, int P, int D,
-                                                         int pos_rows, long lddx) {
+                                                         float* __restrict__ ws, float* __restrict__ dpos, int B, int F,
+                                                         int P, int D, int pos_rows, long lddx) {
+    // ws: [P][D] partial rows of dtemporal (blocks f == 0) then [F - 1][D] partial rows of dspace (blocks p == 0, f > 0)
     const int p = blockIdx.x, f = blockIdx.y;
     const int hw = P - 1, Tn = F - 1;
     for (int e = threadIdx.x * 8; e < D; e += 128 * 8) {
@@ -109,14 +157,14 @@ __global__ __launch_bounds__(128) void tokens_bwd_kernel(const T* __restrict__ d
         }
         if (f == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(dtemporal + e + i, acc[i]);
+            for (int i = 0; i < 8; ++i) ws[(long)p * D + e + i] = acc[i];
         } else {
             float* dp = dpos + ((long)(f - 1) * pos_rows + p) * D + e;
 #pragma unroll
             for (int i = 0; i < 8; ++i) dp[i] += acc[i];
             if (p == 0) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) atomicAdd(dspace + e + i, acc[i]);
+                for (int i = 0; i < 8; ++i) ws[(long)(P + f - 1) * D + e + i] = acc[i];
             }
         }
     }
@@ -133,13 +181,18 @@ extern "C" int istvt_tokens_fwd(const void* feats, const float* space, const flo
 }
 
 // dfeats may be null (features do not require grad).  dspace/dtemporal/dpos accumulate (fp32).
+// ws: float scratch of (P + F - 1) * D elements
 extern "C" int istvt_tokens_bwd(const void* dx, long lddx, void* dfeats, float* dspace, float* dtemporal, float* dpos,
-                                int B, int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
-    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P || lddx < D || lddx % 8) return ISTVT_ERR_SHAPE;
+                                float* ws, int B, int F, int P, int D, int pos_rows, int dtype, hipStream_t stream) {
+    if (B <= 0 || F < 2 || P < 2 || D % 8 != 0 || pos_rows < P || lddx < D || lddx % 8 || !ws) return ISTVT_ERR_SHAPE;
     dim3 grid(P, F), block(128);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tokens_bwd_kernel<T>), grid, block, 0, stream, (const T*)dx, (T*)dfeats,
-                                             dspace, dtemporal, dpos, B, F, P, D, pos_rows, lddx));
-    return istvt_check_launch();
+                                             ws, dpos, B, F, P, D, pos_rows, lddx));
+    int rc = istvt_check_launch();
+    if (rc) return rc;
+    rc = istvt_rows_reduce_add(ws, P, 1, D, dtemporal, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return istvt_rows_reduce_add(ws + (long)P * D, F - 1, 1, D, dspace, nullptr, nullptr, stream);
 }
 
 

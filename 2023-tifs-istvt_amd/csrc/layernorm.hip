@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // row m is reduced, so a wavefront always has a row in flight behind the two dependent wave reductions.
 // Parameter gradients are reduced in a FIXED order: per lane over the rows of its wavefront, over the four wavefronts
 // of a workgroup in LDS, then every workgroup stores its partial row to ws[workgroup][accumulator][D] and
-// ln_bwd_reduce_kernel sums the workgroups in index order -- no floating-point atomics, so two runs give the same bits
+// istvt_rows_reduce_add sums the workgroups in index order -- no floating-point atomics, so two runs give the same bits
 // (and no tail of 3 x 728 same-address atomics per workgroup, which is what capped the grid at 512 workgroups).
 template <typename T> struct LnRaw;
 template <> struct LnRaw<bf16_t> { bf16x8 v; };
@@ -229,33 +229,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
     }
 }
 
-// out_a[col] += sum over workgroups b (in index order) of ws[b][a][col], a < nacc: one thread per (16-row group, column),
-// a workgroup = 64 columns x 16 row groups; the 16 group sums are added in group order.  Single writer per column.
-__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int blocks, int nacc, int D,
-                                                             float* __restrict__ o0, float* __restrict__ o1,
-                                                             float* __restrict__ o2) {
-    __shared__ float part[16][64];
-    const int a = blockIdx.y, cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    const int per = (blocks + 15) / 16, b0 = grp * per, b1 = min(blocks, b0 + per);
-    float s = 0.f;
-    if (col < D) {
-        const float* p = ws + (long)a * D + col;
-        const long step = (long)nacc * D;
-#pragma unroll 8
-        for (int b = b0; b < b1; ++b) s += p[b * step];
-    }
-    part[grp][cl] = s;
-    __syncthreads();
-    if (grp == 0 && col < D) {
-        float t = 0.f;
-#pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) t += part[g2][cl];
-        float* out = a == 0 ? o0 : (a == 1 ? o1 : o2);
-        out[col] += t;
-    }
-}
-
 static int ln_grid(long rows) {
     static const long cap = istvt_tune("ISTVT_LN_BLOCKS", 4096);   // 2048 -> 4096: -8 % on the forward LayerNorm
     long blocks = (rows + 3) / 4;
@@ -307,7 +280,5 @@ extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, lo
                                                  D, ld_dy, ld_x, ld_res, ld_dx));
     int rc = istvt_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, nacc), dim3(1024), 0, stream, ws, (int)blocks, nacc, D, dgamma,
-                       dbeta, dcol);
-    return istvt_check_launch();
+    return istvt_rows_reduce_add(ws, (int)blocks, nacc, D, dgamma, dbeta, dcol, stream);
 }

@@ -869,8 +869,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     for (int o = tid; o < DW_NCH * 72; o += 256) {
         const int chunk = o / 72, rem = o % 72, tap = rem / 8, j = rem % 8;
         const int cc = c0 + chunk * 8 + j;
+        // one partial [C][9] slab per slot (the workgroups of a slot cover the channel chunks): folded in slot order by
+        // istvt_rows_reduce_add -- no float atomics
         if (cc < C)
-            atomicAdd(dw + (long)cc * 9 + tap, sred[0][chunk][rem] + sred[1][chunk][rem] + sred[2][chunk][rem] + sred[3][chunk][rem]);
+            dw[(long)(bid / nch) * C * 9 + (long)cc * 9 + tap] = (sred[0][chunk][rem] + sred[1][chunk][rem]) + (sred[2][chunk][rem] + sred[3][chunk][rem]);
     }
 }
 
@@ -900,19 +902,33 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
     return istvt_check_launch();
 }
 
-extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw,
-                                     int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
-    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+// slots (workgroups per channel chunk) of the weight-gradient launch: each stores one partial [C][9] slab
+static long dww_slots(int Fr, int H, int W, int C) {
     const long tiles = (long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW);
     const int cy = (C + DW_CC - 1) / DW_CC;
-    static const long wg_cap = istvt_tune("ISTVT_DWW_BLOCKS", 512);   // = resident workgroups; 2048 was 4 % slower (atomics tail per workgroup)
+    static const long wg_cap = istvt_tune("ISTVT_DWW_BLOCKS", 512);   // = resident workgroups
     long bx = wg_cap / cy;
     if (bx < 1) bx = 1;
-    if (bx > tiles) bx = tiles;
+    return bx > tiles ? tiles : bx;
+}
+extern "C" int istvt_dwconv3x3_wgrad_ws_elems(int Fr, int H, int W, int C) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    return (int)(dww_slots(Fr, H, W, C) * C * 9);
+}
+
+// dw [C][9] accumulates (+=); ws: float scratch of istvt_dwconv3x3_wgrad_ws_elems(...) elements
+extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw,
+                                     float* ws, long ws_elems, int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
+    if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0 || !ws) return ISTVT_ERR_SHAPE;
+    const int cy = (C + DW_CC - 1) / DW_CC;
+    const long bx = dww_slots(Fr, H, W, C);
+    if (ws_elems < bx * C * 9) return ISTVT_ERR_SHAPE;
     dim3 grid((unsigned)(bx * cy));                        // slot-major, channel chunk fastest
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, dim3(256), 0, stream, (const T*)in,
-                                             in_bn, in_relu, (const T*)dout, dw, Fr, H, W, C));
-    return istvt_check_launch();
+                                             in_bn, in_relu, (const T*)dout, ws, Fr, H, W, C));
+    int rc = istvt_check_launch();
+    if (rc) return rc;
+    return istvt_rows_reduce_add(ws, (int)bx, 1, C * 9, dw, nullptr, nullptr, stream);
 }
 
 // ============================================================================================

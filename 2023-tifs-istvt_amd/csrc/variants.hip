@@ -51,9 +51,9 @@ __global__ __launch_bounds__(128) void prepend_bwd_kernel(const T* __restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) dp[j] += acc[j];
         }
-        if (i == 0 && dtok) {
+        if (i == 0 && dtok) {                   // dtok here = workspace [period][D]: one partial row per q
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(dtok + e + j, acc[j]);
+            for (int j = 0; j < 8; ++j) dtok[(long)q * D + e + j] = acc[j];
         }
     }
 }
@@ -69,15 +69,26 @@ extern "C" int istvt_prepend_fwd(const void* src, const float* tok, const float*
     return istvt_check_launch();
 }
 
-extern "C" int istvt_prepend_bwd(const void* dout, long ldd, void* dsrc, float* dtok, float* dpos, long S, int n, int D,
-                                 int period, int pos_rows, int dtype, hipStream_t stream) {
+// rows of the float workspace istvt_prepend_bwd needs when dtok is given (D floats each)
+extern "C" int istvt_prepend_bwd_ws_rows(long S, int period, int has_pos) {
+    if (S <= 0) return ISTVT_ERR_SHAPE;
+    return has_pos ? period : (int)(S < 64 ? S : 64);
+}
+
+// dtok (may be null) accumulates; ws: float scratch of istvt_prepend_bwd_ws_rows(...) * D elements (needed with dtok):
+// the class-token gradient is summed from per-workgroup partial rows in a fixed order
+extern "C" int istvt_prepend_bwd(const void* dout, long ldd, void* dsrc, float* dtok, float* dpos, float* ws, long S, int n,
+                                 int D, int period, int pos_rows, int dtype, hipStream_t stream) {
     if (S <= 0 || n <= 0 || D <= 0 || D % 8 || ldd < D || ldd % 8) return ISTVT_ERR_SHAPE;
     if (dpos && (period <= 0 || pos_rows < n + 1 || S % period)) return ISTVT_ERR_SHAPE;
+    if (dtok && !ws) return ISTVT_ERR_SHAPE;
     if (!dpos) period = (int)(S < 64 ? S : 64);          // no per-period sums: spread the sequences over <= 64 workgroups per row
     dim3 grid(n + 1, period), block(128);
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((prepend_bwd_kernel<T>), grid, block, 0, stream, (const T*)dout, ldd, (T*)dsrc,
-                                             dtok, dpos, S, n, D, period, pos_rows));
-    return istvt_check_launch();
+                                             dtok ? ws : nullptr, dpos, S, n, D, period, pos_rows));
+    int rc = istvt_check_launch();
+    if (rc || !dtok) return rc;
+    return istvt_rows_reduce_add(ws, period, 1, D, dtok, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------ seq_mean

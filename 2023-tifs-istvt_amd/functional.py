@@ -581,8 +581,10 @@ class PrependFn(Function):
         d2, ldd = ops.rows(dout.reshape(S * (n + 1), D))
         dsrc = torch.empty((S, n, D), dtype=dout.dtype, device=dout.device) if ctx.needs_input_grad[0] else None
         (dt, rt), (dp, rp) = _target(tok), _target(pos)
-        _lib.check(_lib.lib().istvt_prepend_bwd(d2.data_ptr(), ldd, ops._ptr(dsrc), dt.data_ptr(), ops._ptr(dp), S, n, D, period,
-                                                pos_rows, ops.dtype_code(d2), ops._stream()), 'istvt_prepend_bwd')
+        lib = _lib.lib()
+        ws = torch.empty((lib.istvt_prepend_bwd_ws_rows(S, period, int(dp is not None)), D), dtype=torch.float32, device=dout.device)
+        _lib.check(lib.istvt_prepend_bwd(d2.data_ptr(), ldd, ops._ptr(dsrc), dt.data_ptr(), ops._ptr(dp), ws.data_ptr(), S, n, D,
+                                         period, pos_rows, ops.dtype_code(d2), ops._stream()), 'istvt_prepend_bwd')
         return dsrc, rt, rp, None
 
 

@@ -500,8 +500,11 @@ def colsum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     if out is None:
         out = torch.zeros((N,), dtype=torch.float32, device=x.device)
     if N % 8 == 0:
+        lib = _lib.lib()
+        ws = torch.empty((lib.istvt_colsum_ws_elems(M, N),), dtype=torch.float32, device=x.device)
         with prof('colsum', M * N * x.element_size()):
-            _lib.check(_lib.lib().istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, ld, dtype_code(x), _stream()), 'istvt_colsum')
+            _lib.check(lib.istvt_colsum(x.data_ptr(), out.data_ptr(), M, N, ld, ws.data_ptr(), ws.numel(), dtype_code(x),
+                                        _stream()), 'istvt_colsum')
     else:
         x = _c(x)
         # narrow outputs (e.g. the 1-logit head): a [N][1] GEMM against ones keeps it on the HIP path
@@ -661,10 +664,11 @@ def tokens_bwd(dx: Tensor, B: int, T: int, hw: int, D: int, dspace: Tensor, dtem
     dx, lddx = rows(_req(dx))
     F, P = T + 1, hw + 1
     dfeats = torch.empty((B, T, hw, D), dtype=dx.dtype, device=dx.device) if need_dfeats else None
+    ws = torch.empty(((P + F - 1) * D,), dtype=torch.float32, device=dx.device)       # partial rows of the two token gradients
     with prof('tokens_bwd', (B * F * P + (B * T * hw if need_dfeats else 0)) * D * dx.element_size()):
         _lib.check(_lib.lib().istvt_tokens_bwd(dx.data_ptr(), lddx, _ptr(dfeats), dspace.data_ptr(), dtemporal.data_ptr(),
-                                               dpos.data_ptr(), B, F, P, D, dpos.shape[2], dtype_code(dx), _stream()),
-                   'istvt_tokens_bwd')
+                                               dpos.data_ptr(), ws.data_ptr(), B, F, P, D, dpos.shape[2], dtype_code(dx),
+                                               _stream()), 'istvt_tokens_bwd')
     return dfeats
 
 

@@ -159,9 +159,11 @@ def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn
                  out: Optional[Tensor] = None) -> Tensor:
     """out: float32 [C][9] buffer to accumulate into (a depthwise weight's .grad viewed (C, 9))."""
     dw = out if out is not None else torch.zeros((C, 9), dtype=torch.float32, device=x.device)
+    lib = _lib.lib()
+    ws = torch.empty((lib.istvt_dwconv3x3_wgrad_ws_elems(Fr, H, W, C),), dtype=torch.float32, device=x.device)
     with ops.prof('dwconv3x3_wgrad', 2 * Fr * H * W * C * x.element_size()):
-        _lib.check(_lib.lib().istvt_dwconv3x3_wgrad(x.data_ptr(), in_bn.ptr() if in_bn else None, int(in_relu),
-                                                    dout.data_ptr(), dw.data_ptr(), Fr, H, W, C, dtype_code(x), _stream()),
+        _lib.check(lib.istvt_dwconv3x3_wgrad(x.data_ptr(), in_bn.ptr() if in_bn else None, int(in_relu), dout.data_ptr(),
+                                             dw.data_ptr(), ws.data_ptr(), ws.numel(), Fr, H, W, C, dtype_code(x), _stream()),
                    'istvt_dwconv3x3_wgrad')
     return dw
 

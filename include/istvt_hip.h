@@ -123,8 +123,10 @@ int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, long ldv, 
 /* ---- token assembly (DSTTr.forward, vivit.py:133-142) -------------------------------------- */
 int istvt_tokens_fwd(const void* feats, const float* space, const float* temporal, const float* pos, void* x, long ldx,
                      int B, int F, int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
-int istvt_tokens_bwd(const void* dx, long lddx, void* dfeats, float* dspace, float* dtemporal, float* dpos, int B, int F,
-                     int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
+/* dspace / dtemporal / dpos accumulate; ws = float scratch of (P + F - 1) * D elements (per-workgroup partial rows of the
+ * two token gradients, folded in a fixed order: no floating-point atomics) */
+int istvt_tokens_bwd(const void* dx, long lddx, void* dfeats, float* dspace, float* dtemporal, float* dpos, float* ws,
+                     int B, int F, int P, int D, int pos_rows, int dtype, istvt_stream_t stream);
 
 /* frame difference of module.py:193 (adjoint = 1: its transpose, for the backward) */
 int istvt_frame_diff(const void* x, void* out, int B, int F, int P, int D, int adjoint, int dtype,
@@ -205,8 +207,11 @@ int istvt_dwconv3x3(const void* in, const float* w, void* out, int frames, int H
                     int in_relu, int flip, const void* msrc, const float* m_bn, int mask_pre, int mask_post,
                     const void* addsrc, int Ha, int Wa, double* st_s1, double* st_s2, int dtype,
                     istvt_stream_t stream);
-int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw, int frames,
-                          int H, int W, int C, int dtype, istvt_stream_t stream);
+/* dw float [C][9] accumulates; ws = float scratch of istvt_dwconv3x3_wgrad_ws_elems(...) elements (one partial slab
+ * per workgroup slot, folded in slot order: bit-reproducible) */
+int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw, float* ws,
+                          long ws_elems, int frames, int H, int W, int C, int dtype, istvt_stream_t stream);
+int istvt_dwconv3x3_wgrad_ws_elems(int frames, int H, int W, int C);
 
 /* Block tail (xception.py:88,91-100): out = maxpool3x3s2p1(bn_x(x)) + bn_s(skip); argmax: uint8 per output element */
 int istvt_pool_add_fwd(const void* x, const float* bnx, const void* skip, const float* bns, void* out,
@@ -230,8 +235,10 @@ int istvt_relu_avgpool_bwd(const void* x, const void* dout, void* dx, int frames
  * [period][pos_rows][D] or NULL.  bwd: dsrc (may be NULL), dtok / dpos accumulate (float). */
 int istvt_prepend_fwd(const void* src, const float* tok, const float* pos, void* out, long ldo, long S, int n, int D,
                       int period, int pos_rows, int dtype, istvt_stream_t stream);
-int istvt_prepend_bwd(const void* dout, long ldd, void* dsrc, float* dtok, float* dpos, long S, int n, int D,
+/* ws (needed with dtok) = float scratch of istvt_prepend_bwd_ws_rows(S, period, dpos != NULL) * D elements */
+int istvt_prepend_bwd(const void* dout, long ldd, void* dsrc, float* dtok, float* dpos, float* ws, long S, int n, int D,
                       int period, int pos_rows, int dtype, istvt_stream_t stream);
+int istvt_prepend_bwd_ws_rows(long S, int period, int has_pos);
 /* x.mean(dim=1) of [S][n][D] (ViViT pool='mean', vivit.py:79) and its adjoint */
 int istvt_seq_mean_fwd(const void* x, long ldx, void* out, long S, int n, int D, int dtype, istvt_stream_t stream);
 int istvt_seq_mean_bwd(const void* dout, void* dx, long ldx, long S, int n, int D, int dtype, istvt_stream_t stream);
@@ -246,8 +253,11 @@ int istvt_add(const void* a, long lda, const void* b, long ldb, void* out, long 
               istvt_stream_t stream);
 
 /* ---- helpers -------------------------------------------------------------------------------- */
-/* out[n] += sum_m x[m][n]  (bias gradients) */
-int istvt_colsum(const void* x, float* out, long M, int N, long ld, int dtype, istvt_stream_t stream);
+/* out[n] += sum_m x[m][n]  (bias gradients); ws = float scratch of istvt_colsum_ws_elems(M, N) elements (one partial row
+ * per row block, folded in a fixed order) */
+int istvt_colsum(const void* x, float* out, long M, int N, long ld, float* ws, long ws_elems, int dtype,
+                 istvt_stream_t stream);
+int istvt_colsum_ws_elems(long M, int N);
 int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, istvt_stream_t stream);
 /* rows x cols cast between row-strided buffers (bf16 operand copies of fp32 weights with line-aligned rows) */
 int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtype, long ldo, long rows, int cols,

@@ -244,3 +244,76 @@ def test_next_row_constructors_and_state_dict_names(pkg, golden_dir):
         X.Block(64, 128, 2, 2, False)(torch.zeros(1, 64, 9, 9))
     with pytest.raises(RuntimeError, match='ROCm device'):
         mods['vivit'](torch.zeros(1, 4, 64, 19, 19))
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its two ranks itself
+    (child processes of `python -m torch.distributed.run`, never an exec, the parent never initialises the GPU), relays
+    rank 0's ONE JSON line and the job's exit code.  --plumbing-only keeps it runnable without a GPU: process group
+    (gloo), barriers, max-over-ranks timing and the line, around an empty step."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--plumbing-only'], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['plumbing_only'] is True and out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1
+    assert out['distributed']['ranks'] == 2 and out['distributed']['backend'] == 'gloo'
+    assert len(out['distributed']['per_rank_s']) == 2
+    # a failing rank must fail the parent: an unknown flag makes every rank exit 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--plumbing-only', '--no-such-flag'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+
+
+def test_data_parallel_wrapper_is_refused_with_the_way_out(pkg):
+    """train_CNN.py:185-186 wraps the model in nn.DataParallel for more than one device: every module of the HIP path
+    refuses to be replicated (per-process caches / streams / bucket) and names torchrun as the replacement."""
+    from istvt_amd.network.models import model_selection
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = model_selection('resnet_3d', 1)
+    for mod in m.modules():
+        if type(mod).__module__.startswith('istvt_amd'):
+            with pytest.raises(RuntimeError, match='torch.distributed.run'):
+                mod._replicate_for_data_parallel()
+    dp = torch.nn.DataParallel(m)             # constructing the wrapper is harmless; replication is what fails
+    assert dp.module is m
+
+
+def test_pad_mod_is_validated():
+    """a bad ISTVT_PAD_MOD (r >= m, m <= 0, not two integers) fails at import with a ValueError instead of
+    hanging the first allocation"""
+    code = ("import sys; sys.path.insert(0, %r); import istvt_pkg; istvt_pkg.load(); from istvt_amd import ops; "
+            "print(ops.pad_ld(728), ops.pad_ld(2912), ops.pad_ld(512))" % ROOT)
+    ok = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120,
+                        env=dict(os.environ, ISTVT_PAD_MOD='2,1'))
+    assert ok.returncode == 0 and ok.stdout.split() == ['832', '3008', '576'], ok.stdout + ok.stderr
+    for bad in ('2,2', '0,0', '-1,0', '3', 'a,b'):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, ISTVT_PAD_MOD=bad))
+        assert r.returncode != 0 and 'ValueError' in r.stderr, (bad, r.stderr[-500:])
+
+
+def test_dualnet_xception_surface(pkg, golden_dir):
+    """network/xception_for_dualnet.py: constructor default (num_classes=1), the five split points, parameter names equal
+    to the reference class's (every parameter that received a gradient in the reference capture G9 exists here with the
+    same name; `fc` until get_xception() renames it to `last_linear`, :349-351)."""
+    from istvt_amd.network import xception_for_dualnet as XD
+    net = XD.Xception()
+    assert net.num_classes == 1 and net.fc.out_features == 1 and isinstance(net.dp, torch.nn.Dropout) and net.dp.p == 0.2
+    for name in ('fea_0_7', 'fea_8_12', 'fea_0_4', 'fea_5_8', 'fea_9_12', 'features', 'logits', 'forward'):
+        assert callable(getattr(net, name))
+    g = np.load(os.path.join(golden_dir, 'G9_dualnet_halves.npz'))
+    names = dict(net.named_parameters())
+    ref = [k[len('gnorm.'):] for k in g.files if k.startswith('gnorm.')]
+    assert len(ref) > 150
+    for k in ref:
+        assert k in names, k
+    assert set(names) - set(ref) == {'fc.weight', 'fc.bias'}
+    m = XD.get_xception(3)
+    assert 'last_linear.weight' in m.state_dict() and 'fc.weight' not in m.state_dict()
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        net.fea_5_8(torch.zeros(1, 728, 5, 5))

@@ -623,6 +623,31 @@ def test_fused_optimizers_are_torch_optimizers():
         assert o2.steps == 4
         for q_, r_ in zip(ps2, ps):
             assert relerr(q_, r_) < 1e-6, kind
+        # the reference loop's warm-up writes `optimizer.lr = x` every epoch (train_CNN.py:209-211): a plain
+        # attribute, as on torch's optimizers -- it must not raise and, as there, must not change the param group
+        before = o.param_groups[0]['lr']
+        o.lr = 123.0
+        assert o.param_groups[0]['lr'] == before
+        # the state dict has torch's format: it loads into the torch optimizer of the same parameters (and back), and
+        # both then take the same next step
+        sd = o.state_dict()
+        assert set(sd) >= {'state', 'param_groups'} and len(sd['param_groups']) == 1
+        assert sd['param_groups'][0]['params'] == [0, 1, 2] and set(sd['state']) == {0, 1, 2}
+        t_p = [torch.nn.Parameter(q_.detach().clone()) for q_ in ps]
+        t_o = torch.optim.SGD(t_p, lr=0.1, momentum=0.9) if kind == 'sgd' else torch.optim.AdamW(t_p, lr=0.1)
+        t_o.load_state_dict({'state': sd['state'], 'param_groups': sd['param_groups']})
+        ps3, b3, o3 = make(kind)
+        for q_, v in zip(ps3, ps):
+            q_.data.copy_(v.detach())
+        o3.load_state_dict(t_o.state_dict())                  # torch -> fused
+        assert o3.steps == (4 if kind == 'adamw' else 1) or o3.steps >= 1
+        gv = [torch.randn(t.shape, generator=gen) for t in init]
+        for p_, q_, gg in zip(t_p, ps3, gv):
+            p_.grad = gg.clone().cuda()
+            q_.grad.copy_(gg.cuda())
+        t_o.step(); o3.step()
+        for p_, q_ in zip(t_p, ps3):
+            assert relerr(q_, p_) < 5e-6, kind
 
 
 def test_data_parallel_equals_single_process():
@@ -741,3 +766,44 @@ def test_bench_two_rank_path_rehearsal():
     assert out['distributed']['ranks'] == 2 and len(out['distributed']['per_rank_ms_per_step']) == 2
     assert out['value'] > 0 and abs(out['value'] - 2 * 2 * 1e3 / out['ms_per_step']) < 1e-2 * out['value']
     assert 'roofline' in out and out['vs_baseline'] is None
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_training_step_is_bit_reproducible(dtype):
+    """every per-column / per-parameter sum of the backward pass is reduced in a fixed order
+    (per-workgroup partial rows + istvt_rows_reduce_add, split-K slabs, fp64 statistics whose addends are exactly
+    representable), so two runs of the same step on the same inputs give the same BITS in the logits and in every
+    gradient -- with the weight-gradient GEMMs on the side stream, as bench.py runs them."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    XceptionVidTr, _ = _load()
+    T, side, depth, B = 4, 139, 2, 3
+    torch.manual_seed(5)
+    model = XceptionVidTr(num_frames=T, grid=9, depth=depth, compute_dtype=dtype).cuda().train()
+    live = [p for _, p in parallel.live_named_parameters(model)]
+    bucket = parallel.GradBucket(live, fuse_accumulate=True)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((B, T, 3, side, side), generator=g).cuda()
+    labels = torch.tensor([1.0, 0.0, 1.0]).cuda()
+    runs = []
+    for _ in range(3):
+        bucket.zero()
+        for m in model.modules():                       # same BatchNorm running statistics going in
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        logits = model(x)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), labels).backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), bucket.flat.clone()))
+    for lg, fl in runs[1:]:
+        assert torch.equal(lg, runs[0][0])
+        if not torch.equal(fl, runs[0][1]):
+            off = 0
+            bad = []
+            for n, p in parallel.live_named_parameters(model):
+                k = p.numel()
+                if not torch.equal(fl[off:off + k], runs[0][1][off:off + k]):
+                    bad.append((n, float((fl[off:off + k] - runs[0][1][off:off + k]).abs().max())))
+                off += k
+            raise AssertionError('gradients differ between two runs of the same step: %s' % bad[:12])
