@@ -59,6 +59,7 @@ SIGNATURES = {
     'istvt_wgrad_group_splits': [I, P, P, I],
     'istvt_colsum': [P, P, L, I, L, P, L, I, P],
     'istvt_colsum_ws_elems': [L, I],
+    'istvt_rows_reduce': [P, I, L, P, P],
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
     'istvt_cast_transpose': [P, L, P, L, P, L, I, I, P],

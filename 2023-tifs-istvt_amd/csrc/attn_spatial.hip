@@ -25,7 +25,12 @@
 
 constexpr int CHUNK = 128;          // rows of an LDS image
 constexpr int NT = CHUNK / 16;      // 16-row tiles per chunk
-constexpr int IPAD = 8;             // row padding (elements)
+// Row pitch of an LDS image, in elements.  bfloat16: DH + 16 (DH = 64: 160 bytes = 40 banks): eight consecutive rows
+// then start on the eight distinct multiples of 8 banks, so a ds_read_b64_tr_b16 half-wave (8 rows x 32 bytes) and a
+// ds_read_b128 lane group (16 rows x 16 bytes) each touch all 64 banks exactly once.  DH + 8 (144 bytes = 36 banks) put
+// row 7 on top of row 0's first four banks: every transposed read and most row reads were 2-way conflicts (PMC round 2:
+// SQ_LDS_BANK_CONFLICT = 43 % of the LDS cycles of these kernels).  float32 keeps DH + 8 (72 dwords = 8 mod 64).
+template <typename T, int DH> struct Pitch { static constexpr int v = DH + (sizeof(T) == 2 ? 16 : 8); };
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -33,7 +38,7 @@ constexpr int IPAD = 8;             // row padding (elements)
 // rows >= nrows
 template <typename T, int DH, int NTHR = 256>
 __device__ __forceinline__ void stage_img(T* img, const T* __restrict__ src, long ld, int row0, int nrows, int tid) {
-    constexpr int LDI = DH + IPAD;
+    constexpr int LDI = Pitch<T, DH>::v;
     constexpr int VPR = DH / 8;
     constexpr int NV = CHUNK * VPR / NTHR;
 #pragma unroll
@@ -71,14 +76,15 @@ __device__ __forceinline__ void stage_fetch(StageRegs<T, DH, NTHR>& rg, const T*
     }
 }
 template <typename T, int DH, int NTHR>
-__device__ __forceinline__ void stage_commit(T* img, const StageRegs<T, DH, NTHR>& rg, int tid) {
-    constexpr int LDI = DH + IPAD;
+__device__ __forceinline__ void stage_commit(T* img, const StageRegs<T, DH, NTHR>& rg, int tid, int rlim = CHUNK) {
+    constexpr int LDI = Pitch<T, DH>::v;
     constexpr int VPR = DH / 8;
     constexpr int NV = CHUNK * VPR / NTHR;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + NTHR * i;
         const int row = v / VPR, col = (v % VPR) * 8;
+        if (row >= rlim) continue;                       // rows the image does not have (RES: images of img_rows rows)
         if constexpr (sizeof(T) == 2) {
             *reinterpret_cast<bf16x8*>(img + row * LDI + col) = rg.f[i];
         } else {
@@ -93,8 +99,8 @@ __device__ __forceinline__ void stage_commit(T* img, const StageRegs<T, DH, NTHR
 // first LDS store (stage_img's load -> store pairs made the two matrices two dependent memory round trips)
 template <typename T, int DH, int NTHR, int NCH>
 __device__ __forceinline__ void stage_all2(T* imgA, const T* __restrict__ srcA, long ldA, T* imgB, const T* __restrict__ srcB,
-                                           long ldB, int P, int tid) {
-    constexpr int LDI = DH + IPAD;
+                                           long ldB, int P, int tid, int img_rows) {
+    constexpr int LDI = Pitch<T, DH>::v;
     StageRegs<T, DH, NTHR> ra[NCH], rb[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -106,8 +112,8 @@ __device__ __forceinline__ void stage_all2(T* imgA, const T* __restrict__ srcA, 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch * CHUNK < P) {
-            stage_commit(imgA + ch * CHUNK * LDI, ra[ch], tid);
-            stage_commit(imgB + ch * CHUNK * LDI, rb[ch], tid);
+            stage_commit(imgA + ch * CHUNK * LDI, ra[ch], tid, img_rows - ch * CHUNK);
+            stage_commit(imgB + ch * CHUNK * LDI, rb[ch], tid, img_rows - ch * CHUNK);
         }
     }
 }
@@ -159,15 +165,20 @@ __device__ __forceinline__ float group_sum(float v) { return xgroup_sum(v); }
 // V fetched twice, 1.57x the algorithmic bytes by the PMC pass; the kernel is bound by that traffic).  After the one
 // barrier behind the staging the wavefronts run independently: no chunk barriers, no re-staging.
 constexpr int RES_CHUNKS = 2;
+// RES kernels: the two LDS images hold img_rows = P rounded up to 32 rows (zero-filled past P), in dynamic shared memory
+// sized by the host -- P = 197: 2 x 224 rows x 160 bytes = 70 KiB, two workgroups per CU (256-row images at this pitch
+// would be 80 KiB + statistics: one).
+extern __shared__ __attribute__((aligned(16))) char sattn_dyn[];
+__host__ __device__ inline int res_img_rows(int P) { return (P + 31) & ~31; }
 
 template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
 __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         float* __restrict__ lse, int P, int heads, float scale, long ldqkv, long ldo) {
-    constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
-    constexpr int NIMG = RES ? RES_CHUNKS : 1;
-    __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
-    T* Kimg = smem;
-    T* Vimg = smem + NIMG * CHUNK * LDI;
+    constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
+    const int img_rows = RES ? res_img_rows(P) : CHUNK;
+    T* Kimg = RES ? reinterpret_cast<T*>(sattn_dyn) : smem_st;
+    T* Vimg = Kimg + img_rows * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
                 qf_pre[qi][u][ks] = row_frag<T>(qp, ld, (RES ? qi : (int)blockIdx.x) * 128 + wave * 16 * U + 16 * u + r, P,
                                                 32 * ks + 8 * g);
     if constexpr (RES) {
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid);
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid, img_rows);
         __syncthreads();
     }
 #pragma unroll
@@ -363,11 +374,11 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv, int P,
                                                            int heads, float scale, long ldqkv, long ldo) {
-    constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
-    constexpr int NIMG = RES ? RES_CHUNKS : 1;
-    __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
-    T* Kimg = smem;
-    T* Vimg = smem + NIMG * CHUNK * LDI;
+    constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
+    const int img_rows = RES ? res_img_rows(P) : CHUNK;
+    T* Kimg = RES ? reinterpret_cast<T*>(sattn_dyn) : smem_st;
+    T* Vimg = Kimg + img_rows * LDI;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
             st_pre[qi][u] = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
         }
     if constexpr (RES) {                               // every key / value row staged once (see sattn_fwd_kernel)
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid);
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid, img_rows);
         __syncthreads();
     }
 #pragma unroll
@@ -518,12 +529,14 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
                                                             int P, int heads, float scale, long ldqkv, long ldo) {
-    constexpr int LDI = DH + IPAD, KS = DH / 32, DT = DH / 16;
-    constexpr int NIMG = RES ? RES_CHUNKS : 1;
-    __shared__ __attribute__((aligned(16))) T smem[2 * NIMG * CHUNK * LDI];
-    __shared__ __attribute__((aligned(16))) float stat_s[2][NIMG * CHUNK];
-    T* Qimg = smem;
-    T* Dimg = smem + NIMG * CHUNK * LDI;
+    constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
+    __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
+    __shared__ __attribute__((aligned(16))) float stat_st[RES ? 4 : 2 * CHUNK];
+    const int img_rows = RES ? res_img_rows(P) : CHUNK;
+    T* Qimg = RES ? reinterpret_cast<T*>(sattn_dyn) : smem_st;
+    T* Dimg = Qimg + img_rows * LDI;
+    float* stat0 = RES ? reinterpret_cast<float*>(Dimg + img_rows * LDI) : stat_st;     // exponent offsets, then deltas
+    float* stat1 = stat0 + img_rows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
     const int prob = blockIdx.y, h = prob % heads, bf = prob / heads;
     const int inner = heads * DH;
@@ -548,11 +561,11 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
                 vf_pre[ki][kt][ks] = row_frag<T>(vp, ld, key, P, 32 * ks + 8 * g);
             }
     if constexpr (RES) {                               // every query / dO row and its statistics staged once
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, ldo, P, tid);
-        for (int q = tid; q < NIMG * CHUNK; q += 512 / U) {
+        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, ldo, P, tid, img_rows);
+        for (int q = tid; q < img_rows; q += 512 / U) {
             const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
-            stat_s[0][q] = st.x - __builtin_amdgcn_logf(st.y);       // exponent offset incl. log2(1/sum); +inf for padding
-            stat_s[1][q] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
+            stat0[q] = st.x - __builtin_amdgcn_logf(st.y);       // exponent offset incl. log2(1/sum); +inf for padding
+            stat1[q] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
         }
         __syncthreads();
     }
@@ -599,8 +612,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
             stage_commit(Qimg, qreg, tid);
             stage_commit(Dimg, dreg, tid);
             if (tid < CHUNK) {
-                stat_s[0][tid] = streg.x - __builtin_amdgcn_logf(streg.y);    // exponent offset incl. log2(1/sum); +inf for padding
-                stat_s[1][tid] = dlreg;
+                stat0[tid] = streg.x - __builtin_amdgcn_logf(streg.y);    // exponent offset incl. log2(1/sum); +inf for padding
+                stat1[tid] = dlreg;
             }
             __syncthreads();
             if (c0 + CHUNK < P) fetch(c0 + CHUNK);
@@ -608,8 +621,8 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
         }
         const T* const Qimg_c = RES ? Qimg + (c0 / CHUNK) * CHUNK * LDI : Qimg;
         const T* const Dimg_c = RES ? Dimg + (c0 / CHUNK) * CHUNK * LDI : Dimg;
-        const float* const st0 = RES ? &stat_s[0][c0] : &stat_s[0][0];
-        const float* const st1 = RES ? &stat_s[1][c0] : &stat_s[1][0];
+        const float* const st0 = RES ? stat0 + c0 : stat0;
+        const float* const st1 = RES ? stat1 + c0 : stat1;
 #pragma unroll
         for (int ss = 0; ss < NT / 2; ++ss) {
             if (c0 + 32 * ss >= P) continue;
@@ -684,6 +697,25 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
         else return ISTVT_ERR_SHAPE;                            \
     } while (0)
 
+// RES launches: dynamic LDS = two images of res_img_rows(P) rows (+ two float statistics rows for the dK / dV kernel);
+// above 64 KiB the kernel needs its limit raised once (hipFuncSetAttribute).
+template <typename K>
+static int res_lds(K kernel, int P, int dh, bool with_stats, size_t* bytes) {
+    const size_t b = 2ul * res_img_rows(P) * (dh + 16) * sizeof(bf16_t) + (with_stats ? 2ul * res_img_rows(P) * sizeof(float) : 0);
+    *bytes = b;
+    if (b > 65536 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b) != hipSuccess)
+        return ISTVT_ERR_LAUNCH;
+    return ISTVT_OK;
+}
+#define LAUNCH_RES(KERNEL, STATS, ...)                                                            \
+    do {                                                                                          \
+        size_t lds_ = 0;                                                                          \
+        const int rc_ = res_lds(KERNEL, P, dh, STATS, &lds_);                                     \
+        if (rc_) return rc_;                                                                      \
+        hipLaunchKernelGGL(KERNEL, dim3(1, BF * heads), dim3(512), lds_, stream, __VA_ARGS__);    \
+    } while (0)
+
 // qkv: [BF*P][3*heads*dh]; out: [BF*P][heads*dh]; lse: [BF*P][heads][2] = (row max in the log2 domain, 1/rowsum)
 extern "C" int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, long ldo, float* lse, int BF, int P, int heads, int dh,
                                       float scale, int dtype, hipStream_t stream) {
@@ -693,8 +725,8 @@ extern "C" int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, lo
     // bf16: 8 wavefronts x 16 queries (more wavefronts per SIMD); fp32 keeps 4 x 32 (its LDS image fills the CU)
     if (dtype == DT_BF16) {
         if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {      // one workgroup per (frame, head), keys resident (P = 197 at 224^2)
-            DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, false, true>), dim3(1, BF * heads), dim3(512), 0,
-                                               stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale, ldqkv, ldo));
+            DISPATCH_DH(dh, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, false, true>), false, (const bf16_t*)qkv, (bf16_t*)out, lse,
+                                       P, heads, scale, ldqkv, ldo));
             return istvt_check_launch();
         }
         DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream,
@@ -715,12 +747,11 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, long ldqkv, const void* o
     if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
     if (dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        const dim3 g1(1, BF * heads);
         DISPATCH_DH(dh, {
-            hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
-            hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, false, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
+            LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, true>), false, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
+            LAUNCH_RES((sattn_bwd_dkv_kernel<bf16_t, DH, 1, false, true>), true, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
         });
         return istvt_check_launch();
     }
@@ -753,8 +784,8 @@ extern "C" int istvt_attn_spatial_fwd_fp8(const void* qkv, long ldqkv, void* out
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
     if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true, true>), dim3(1, BF * heads), dim3(512), 0,
-                                           stream, (const bf16_t*)qkv, (bf16_t*)out, lse, P, heads, scale, ldqkv, ldo));
+        DISPATCH_DH(dh, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, true, true>), false, (const bf16_t*)qkv, (bf16_t*)out, lse, P,
+                                   heads, scale, ldqkv, ldo));
         return istvt_check_launch();
     }
     DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream,
@@ -770,12 +801,11 @@ extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const voi
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
     if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        const dim3 g1(1, BF * heads);
         DISPATCH_DH(dh, {
-            hipLaunchKernelGGL((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
-            hipLaunchKernelGGL((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true, true>), g1, dim3(512), 0, stream, (const bf16_t*)qkv,
-                               (const bf16_t*)dout, lse, (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
+            LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, true>), false, (const bf16_t*)qkv, (const bf16_t*)out,
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
+            LAUNCH_RES((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true, true>), true, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
         });
         return istvt_check_launch();
     }

@@ -84,56 +84,86 @@ __device__ __forceinline__ void stage32(bf16_t* img, const bf16_t* __restrict__ 
         *reinterpret_cast<bf16x8*>(img + row * LDI + col) = row_frag(src, rstride, row, nrows, col);
     }
 }
-// ---- the frame difference of module.py:193 on projected rows (see attn_temporal.hip) ---------------------------------
-// Fragment layout: lane (g, r) holds row 16 t + r of a tile.  Row r - 1 is lane r - 1 of the same 16-lane DPP row
-// (row_shr:1); lane r = 0 receives row 15 of the tile BELOW (row_ror:1 of that tile's fragment).
-__device__ __forceinline__ bf16x8 prev_row_frag(const bf16x8& cur, const bf16x8& below) {
-    const u32x4 c = __builtin_bit_cast(u32x4, cur), b = __builtin_bit_cast(u32x4, below);
-    u32x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned wrap = __builtin_amdgcn_update_dpp(0u, b[i], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
-        o[i] = __builtin_amdgcn_update_dpp(wrap, c[i], 0x111 /* row_shr:1: lane 0 keeps `wrap` */, 0xf, 0xf, false);
-    }
-    return __builtin_bit_cast(bf16x8, o);
+// ---- the frame difference of module.py:193, taken on the SCORES --------------------------------------------------
+// q'[f] = q[f] - q[f-1], k'[f] = k[f] - k[f-1] for f >= 2 (frames 0, 1 unchanged) means S' = D S D^T with S = Q K^T of the
+// UN-differenced rows and D the F x F difference operator: the wavefront differences its F x F score tile along both
+// axes in fp32 (a handful of DPP moves and subtractions) instead of ~100 conversions on the bf16 operand fragments, the
+// difference is exact (no second rounding of q' / k' to bf16), and the backward needs no adjoint on [F][DH] outputs: with
+// dS = D^T dS' D the gradients dQ = dS K, dK = dS^T Q come out with respect to the un-differenced rows directly.
+// A tile set x[NA][NB] of 16x16 accumulator tiles: element (a, b, j) of lane (g, r) has row index rho = 16a + 4g + j (the
+// accumulator-row axis) and column index kappa = 16b + r (the lane axis).
+__device__ __forceinline__ float lane_from(float v, int src_lane) {          // value of `v` in lane src_lane (LDS crossbar, no memory)
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
-// x'[f] = x[f] - x[f-1] for f >= 2 (rounded once to bf16, the MFMA operand type)
-__device__ __forceinline__ bf16x8 diff_frag(const bf16x8& cur, const bf16x8& prev, const int f) {
-    bf16x8 o;
+// y = D x along the lane axis: y[kappa] = x[kappa] - x[kappa - 1] for kappa >= 2
+template <int NA, int NB>
+__device__ __forceinline__ void diff_lanes(f32x4 (&x)[NA][NB], int r) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = f >= 2 ? (bf16_t)((float)cur[i] - (float)prev[i]) : cur[i];
-    return o;
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = NB - 1; b >= 0; --b)                      // top tile first: the tile below is still un-differenced
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned below = __float_as_uint(x[a][b > 0 ? b - 1 : 0][j]);
+                const unsigned wrap = __builtin_amdgcn_update_dpp(0u, below, 0x121 /* row_ror:1: lane 0 <- lane 15 */, 0xf, 0xf, true);
+                const unsigned pv = __builtin_amdgcn_update_dpp(wrap, __float_as_uint(x[a][b][j]), 0x111 /* row_shr:1; lane 0 keeps wrap */, 0xf, 0xf, false);
+                if (16 * b + r >= 2) x[a][b][j] -= __uint_as_float(pv);
+            }
 }
-// accumulator layout: lane (g, r) holds row 16 u + r.  Row r + 1 is lane r + 1 (row_shl:1); lane 15 receives row 0 of
-// the tile ABOVE.  The adjoint of the difference: d x[f] = d x'[f] - d x'[f+1] for f + 1 >= 2.
-__device__ __forceinline__ f32x4 diff_adjoint_acc(const f32x4& cur, const f32x4& above, const int f) {
-    f32x4 o;
+// y = D^T x along the lane axis: y[kappa] = x[kappa] - x[kappa + 1] for kappa >= 1 (x beyond the last tile is zero)
+template <int NA, int NB>
+__device__ __forceinline__ void adj_lanes(f32x4 (&x)[NA][NB], int r) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned wrap = __builtin_amdgcn_update_dpp(0u, __float_as_uint(above[i]), 0x12F /* row_ror:15 */, 0xf, 0xf, true);
-        const unsigned nx = __builtin_amdgcn_update_dpp(wrap, __float_as_uint(cur[i]), 0x101 /* row_shl:1: lane 15 keeps `wrap` */, 0xf, 0xf, false);
-        o[i] = f >= 1 ? cur[i] - __uint_as_float(nx) : cur[i];
-    }
-    return o;
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)                           // bottom tile first: the tile above is still untouched
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned above = b + 1 < NB ? __float_as_uint(x[a][b + 1 < NB ? b + 1 : b][j]) : 0u;
+                const unsigned wrap = __builtin_amdgcn_update_dpp(0u, above, 0x12F /* row_ror:15: lane 15 <- lane 0 */, 0xf, 0xf, true);
+                const unsigned nx = __builtin_amdgcn_update_dpp(wrap, __float_as_uint(x[a][b][j]), 0x101 /* row_shl:1; lane 15 keeps wrap */, 0xf, 0xf, false);
+                if (16 * b + r >= 1) x[a][b][j] -= __uint_as_float(nx);
+            }
 }
-// the difference applied in place to a staged [16 NTL][DH + IPAD] image (one wavefront): every lane holds its 8-element
-// chunk of row `row` in `mine` (as staged), reads the chunk of the row above it in the frame order from the image,
-// and -- after every lane has read -- overwrites its own
-template <int DH, int NTL>
-__device__ __forceinline__ void diff_image(bf16_t* img, const bf16x8 (&mine)[16 * NTL / (64 / (DH / 8))], int lane) {
-    constexpr int LDI = DH + IPAD, VPR = DH / 8, RPI = 64 / VPR, NIT = 16 * NTL / RPI;
-    bf16x8 prev[NIT];
+// y = D x along the accumulator-row axis: y[rho] = x[rho] - x[rho - 1] for rho >= 2.  Row rho - 1 of register j = 0 is
+// register 3 of the lane 16 below (lane group g - 1), or -- for g = 0 -- register 3 of group 3 in the tile below.
+template <int NA, int NB>
+__device__ __forceinline__ void diff_rows(f32x4 (&x)[NA][NB], int lane) {
+    const int g = lane >> 4;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
-        prev[it] = *reinterpret_cast<const bf16x8*>(img + (row >= 1 ? row - 1 : 0) * LDI + col);
-    }
-    wave_lds_fence();
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int row = it * RPI + lane / VPR, col = (lane % VPR) * 8;
-        *reinterpret_cast<bf16x8*>(img + row * LDI + col) = diff_frag(mine[it], prev[it], row);
-    }
+        for (int a = NA - 1; a >= 0; --a) {
+            const float send = (g == 3 && a > 0) ? x[a > 0 ? a - 1 : 0][b][3] : x[a][b][3];
+            const float recv = lane_from(send, (lane - 16) & 63);
+            const int rho0 = 16 * a + 4 * g;
+            f32x4 y = x[a][b];
+#pragma unroll
+            for (int j = 3; j >= 1; --j)
+                if (rho0 + j >= 2) y[j] = x[a][b][j] - x[a][b][j - 1];
+            if (rho0 >= 2) y[0] = x[a][b][0] - recv;
+            x[a][b] = y;
+        }
+}
+// y = D^T x along the accumulator-row axis: y[rho] = x[rho] - x[rho + 1] for rho >= 1
+template <int NA, int NB>
+__device__ __forceinline__ void adj_rows(f32x4 (&x)[NA][NB], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const float up0 = a + 1 < NA ? x[a + 1 < NA ? a + 1 : a][b][0] : 0.f;
+            const float send = g == 0 ? up0 : x[a][b][0];           // group 0 answers group 3 of the tile below it
+            const float recv = lane_from(send, (lane + 16) & 63);
+            const int rho0 = 16 * a + 4 * g;
+            f32x4 y = x[a][b];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (rho0 + j >= 1) y[j] = x[a][b][j] - x[a][b][j + 1];
+            y[3] = x[a][b][3] - recv;                                // rho0 + 3 >= 1 always
+            x[a][b] = y;
+        }
 }
 }  // namespace tmf
 
@@ -160,53 +190,41 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     const float c = scale * TM_LOG2E;
 
     tmf::stage32<DH, NTL>(Vimg, vp, sv, F, lane);
-    bf16x8 kf[NTL][KS];
+    bf16x8 kf[NTL][KS], qf[NTL][KS];
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
-    if (diff) {                                             // top tile first: the tile below is still un-differenced
-#pragma unroll
-        for (int t = NTL - 1; t >= 0; --t)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                kf[t][ks] = tmf::diff_frag(kf[t][ks], tmf::prev_row_frag(kf[t][ks], kf[t > 0 ? t - 1 : 0][ks]), 16 * t + r);
-    }
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[t][ks] = tmf::row_frag(kp, sq, 16 * t + r, F, 32 * ks + 8 * g);
+            qf[t][ks] = tmf::row_frag(qp, sq, 16 * t + r, F, 32 * ks + 8 * g);
+        }
     tmf::wave_lds_fence();
 
-    bf16x8 qbelow[KS];                                      // the un-differenced query rows of the previous tile
+    // S^T = K Q^T for every (key tile t, query tile u): rows = keys 16t + 4g + j, lanes = queries 16u + r
+    f32x4 s[NTL][NTL];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qbelow[ks] = tmf::zero8();
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+            s[t][u] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) tmf::mma(s[t][u], kf[t][ks], qf[u][ks]);
+        }
+    if (diff) {                                            // S' = D S D^T (see the helpers above)
+        tmf::diff_lanes<NTL, NTL>(s, r);
+        tmf::diff_rows<NTL, NTL>(s, lane);
+    }
 #pragma unroll
     for (int u = 0; u < NTL; ++u) {
         if (16 * u >= F) break;
-        bf16x8 qf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = tmf::row_frag(qp, sq, 16 * u + r, F, 32 * ks + 8 * g);
-        if (diff) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 raw = qf[ks];
-                qf[ks] = tmf::diff_frag(raw, tmf::prev_row_frag(raw, qbelow[ks]), 16 * u + r);
-                qbelow[ks] = raw;
-            }
-        }
-        f32x4 s[2];
-        s[1] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-            s[t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) tmf::mma(s[t], kf[t][ks], qf[ks]);
-        }
         // softmax over keys: lane owns query r, keys 16t + 4g + j
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float z = (16 * t + 4 * g + j) < F ? s[t][j] * c : -INFINITY;
-                s[t][j] = z;
+                const float z = (16 * t + 4 * g + j) < F ? s[t][u][j] * c : -INFINITY;
+                s[t][u][j] = z;
                 mx = fmaxf(mx, z);
             }
         mx = tmf::group_max(mx);
@@ -215,8 +233,8 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
         for (int t = 0; t < NTL; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float pv = fast_exp2(s[t][j] - mx);
-                s[t][j] = pv;
+                const float pv = fast_exp2(s[t][u][j] - mx);
+                s[t][u][j] = pv;
                 sum += pv;
             }
         sum = tmf::group_sum(sum);
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             f32x4 o = f32x4{0, 0, 0, 0};
-            tmf::mma_frames<NTL>(o, Vimg, LDI, 16 * dt, g, r, s[0], s[1]);
+            tmf::mma_frames<NTL>(o, Vimg, LDI, 16 * dt, g, r, s[0][u], s[NTL - 1][u]);
             if (q < F) {
                 float ov[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
                 store4(op + (long)q * so + 16 * dt + 4 * g, ov);
@@ -295,147 +313,151 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         *reinterpret_cast<bf16x8*>(Kimg + row * LDI + col) = nk[it];
         *reinterpret_cast<bf16x8*>(Dimg + row * LDI + col) = nd[it];
     }
-    bf16x8 kf[NTL][KS], vf[NTL][KS];
+    bf16x8 kf[NTL][KS], vf[NTL][KS], qf[NTL][KS], dof[NTL][KS];
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) vf[t][ks] = nv[t][ks];
     tmf::wave_lds_fence();
-    if (diff) {                                           // Q, K images -> differenced in place (nq / nk still hold the rows)
-        tmf::diff_image<DH, NTL>(Qimg, nq, lane);
-        tmf::diff_image<DH, NTL>(Kimg, nk, lane);
-        tmf::wave_lds_fence();
-    }
     if (prob + nwaves < total) fetch(prob + nwaves);
-    // K rows in fragment layout (row 16t + r, columns 32ks + 8g), from the image
+    // Q, K, dO rows in fragment layout (row 16t + r, columns 32ks + 8g), from the images
 #pragma unroll
     for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            kf[t][ks] = *reinterpret_cast<const bf16x8*>(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
-
-    // ---- part 1: per query tile u -- S^T, dP^T (keys on rows, queries on lanes), statistics, dQ
-    f32x4 above[DT];                                      // diff: d q' of the tile above (its row 0 closes row 15 below)
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) above[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int u = NTL - 1; u >= 0; --u) {
-        if (16 * u >= F) continue;
-        const int q = 16 * u + r;
-        bf16x8 qf[KS], dof[KS];
-#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *reinterpret_cast<const bf16x8*>(Qimg + q * LDI + 32 * ks + 8 * g);
-            dof[ks] = *reinterpret_cast<const bf16x8*>(Dimg + q * LDI + 32 * ks + 8 * g);
+            kf[t][ks] = *reinterpret_cast<const bf16x8*>(Kimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
+            qf[t][ks] = *reinterpret_cast<const bf16x8*>(Qimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
+            dof[t][ks] = *reinterpret_cast<const bf16x8*>(Dimg + (16 * t + r) * LDI + 32 * ks + 8 * g);
         }
-        f32x4 s[2], dp[2];
-        s[1] = f32x4{0, 0, 0, 0};
+
+    // ---- part 1: S^T, dP^T (keys on rows, queries on lanes) for every (key tile t, query tile u): statistics, dS, dQ
+    {
+        f32x4 s[NTL][NTL], dp[NTL][NTL];
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-            s[t] = f32x4{0, 0, 0, 0}; dp[t] = f32x4{0, 0, 0, 0};
+        for (int t = 0; t < NTL; ++t)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                tmf::mma(s[t], kf[t][ks], qf[ks]);
-                tmf::mma(dp[t], vf[t][ks], dof[ks]);
+            for (int u = 0; u < NTL; ++u) {
+                s[t][u] = f32x4{0, 0, 0, 0}; dp[t][u] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    tmf::mma(s[t][u], kf[t][ks], qf[u][ks]);
+                    tmf::mma(dp[t][u], vf[t][ks], dof[u][ks]);
+                }
             }
+        if (diff) {
+            tmf::diff_lanes<NTL, NTL>(s, r);
+            tmf::diff_rows<NTL, NTL>(s, lane);
         }
-        float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
+        for (int u = 0; u < NTL; ++u) {
+            const int q = 16 * u + r;
+            float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float z = (16 * t + 4 * g + j) < F ? s[t][j] * c : -INFINITY;
-                s[t][j] = z;
-                mx = fmaxf(mx, z);
-            }
-        mx = tmf::group_max(mx);
-        float sum = 0.f;
+            for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
+                for (int j = 0; j < 4; ++j) {
+                    const float z = (16 * t + 4 * g + j) < F ? s[t][u][j] * c : -INFINITY;
+                    s[t][u][j] = z;
+                    mx = fmaxf(mx, z);
+                }
+            mx = tmf::group_max(mx);
+            float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float pv = fast_exp2(s[t][j] - mx);
-                s[t][j] = pv;
-                sum += pv;
-            }
-        sum = tmf::group_sum(sum);
-        const float inv = 1.0f / sum;
-        float dl = 0.f;
+            for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
+                for (int j = 0; j < 4; ++j) {
+                    const float pv = fast_exp2(s[t][u][j] - mx);
+                    s[t][u][j] = pv;
+                    sum += pv;
+                }
+            sum = tmf::group_sum(sum);
+            const float inv = 1.0f / sum;
+            float dl = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s[t][j] *= inv; dl += s[t][j] * dp[t][j]; }
-        dl = tmf::group_sum(dl);
+            for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
+                for (int j = 0; j < 4; ++j) { s[t][u][j] *= inv; dl += s[t][u][j] * dp[t][u][j]; }
+            dl = tmf::group_sum(dl);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[t][j] = s[t][j] * (dp[t][j] - dl) * scale;        // dS^T
-        if (g == 0) { st[0][q] = mx; st[1][q] = inv; st[2][q] = dl; }                       // rows q >= F: never used (p = 0 there)
+            for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            f32x4 dq = f32x4{0, 0, 0, 0};
-            tmf::mma_frames<NTL>(dq, Kimg, LDI, 16 * dt, g, r, s[0], s[1]);
-            if (diff) {                                   // rows >= F carry zero gradients (their dO rows are zero)
-                const f32x4 raw = dq;
-                dq = tmf::diff_adjoint_acc(raw, above[dt], q);
-                above[dt] = raw;
-            }
-            if (q < F) {
-                float o[4] = {dq[0], dq[1], dq[2], dq[3]};
-                store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
+                for (int j = 0; j < 4; ++j) s[t][u][j] = s[t][u][j] * (dp[t][u][j] - dl) * scale;      // dS'^T (query rows >= F: dO = 0 -> 0)
+            if (g == 0) { st[0][q] = mx; st[1][q] = inv; st[2][q] = dl; }                           // rows q >= F: never used (p = 0 there)
+        }
+        if (diff) {                                        // dS = D^T dS' D: the gradient w.r.t. the UN-differenced scores
+            tmf::adj_lanes<NTL, NTL>(s, r);
+            tmf::adj_rows<NTL, NTL>(s, lane);
+        }
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+            if (16 * u >= F) break;
+            const int q = 16 * u + r;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4 dq = f32x4{0, 0, 0, 0};
+                tmf::mma_frames<NTL>(dq, Kimg, LDI, 16 * dt, g, r, s[0][u], s[NTL - 1][u]);
+                if (q < F) {
+                    float o[4] = {dq[0], dq[1], dq[2], dq[3]};
+                    store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
+                }
             }
         }
     }
     tmf::wave_lds_fence();
 
-    // ---- part 2: per key tile kt -- S, dP (queries on rows, keys on lanes) -> dV, dK
-    // B operands of this orientation are the K / V rows of the tile: kf[kt], vf[kt] as loaded above
+    // ---- part 2: S, dP (queries on rows, keys on lanes) for every (query tile tt, key tile kt) -> dV, dK
+    {
+        f32x4 s[NTL][NTL], dp[NTL][NTL];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) above[dt] = f32x4{0, 0, 0, 0};
+        for (int tt = 0; tt < NTL; ++tt)
 #pragma unroll
-    for (int kt = NTL - 1; kt >= 0; --kt) {
-        if (16 * kt >= F) continue;
-        const int key = 16 * kt + r;
-        f32x4 s[2], dp[2];
-        s[1] = f32x4{0, 0, 0, 0}; dp[1] = f32x4{0, 0, 0, 0};
+            for (int kt = 0; kt < NTL; ++kt) {
+                s[tt][kt] = f32x4{0, 0, 0, 0}; dp[tt][kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    tmf::mma(s[tt][kt], qf[tt][ks], kf[kt][ks]);
+                    tmf::mma(dp[tt][kt], dof[tt][ks], vf[kt][ks]);
+                }
+            }
+        if (diff) {
+            tmf::diff_lanes<NTL, NTL>(s, r);
+            tmf::diff_rows<NTL, NTL>(s, lane);
+        }
 #pragma unroll
         for (int tt = 0; tt < NTL; ++tt) {
-            s[tt] = f32x4{0, 0, 0, 0}; dp[tt] = f32x4{0, 0, 0, 0};
-            const int qrow = 16 * tt + r;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qimg + qrow * LDI + 32 * ks + 8 * g);
-                const bf16x8 da = *reinterpret_cast<const bf16x8*>(Dimg + qrow * LDI + 32 * ks + 8 * g);
-                tmf::mma(s[tt], qa, kf[kt][ks]);
-                tmf::mma(dp[tt], da, vf[kt][ks]);
-            }
             const int qb = 16 * tt + 4 * g;
             const float4 m4 = *reinterpret_cast<const float4*>(&st[0][qb]);
             const float4 i4 = *reinterpret_cast<const float4*>(&st[1][qb]);
             const float4 d4 = *reinterpret_cast<const float4*>(&st[2][qb]);
             const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = (qb + j) < F && key < F;
-                const float pv = ok ? fast_exp2(s[tt][j] * c - mv[j]) * iv[j] : 0.f;
-                s[tt][j] = pv;                                            // P
-                dp[tt][j] = pv * (dp[tt][j] - dv4[j]) * scale;            // dS
-            }
+            for (int kt = 0; kt < NTL; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = (qb + j) < F && (16 * kt + r) < F;
+                    const float pv = ok ? fast_exp2(s[tt][kt][j] * c - mv[j]) * iv[j] : 0.f;
+                    s[tt][kt][j] = pv;                                            // P
+                    dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]) * scale;        // dS'
+                }
+        }
+        if (diff) {
+            tmf::adj_lanes<NTL, NTL>(dp, r);
+            tmf::adj_rows<NTL, NTL>(dp, lane);
         }
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            f32x4 dvv = f32x4{0, 0, 0, 0}, dkk = f32x4{0, 0, 0, 0};
-            tmf::mma_frames<NTL>(dvv, Dimg, LDI, 16 * dt, g, r, s[0], s[1]);
-            tmf::mma_frames<NTL>(dkk, Qimg, LDI, 16 * dt, g, r, dp[0], dp[1]);
-            if (diff) {
-                const f32x4 raw = dkk;
-                dkk = tmf::diff_adjoint_acc(raw, above[dt], key);
-                above[dt] = raw;
-            }
-            if (key < F) {
-                float a[4] = {dkk[0], dkk[1], dkk[2], dkk[3]}, bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
-                store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
-                store4(dvp + (long)key * sv + 16 * dt + 4 * g, bb);
+        for (int kt = 0; kt < NTL; ++kt) {
+            if (16 * kt >= F) break;
+            const int key = 16 * kt + r;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4 dvv = f32x4{0, 0, 0, 0}, dkk = f32x4{0, 0, 0, 0};
+                tmf::mma_frames<NTL>(dvv, Dimg, LDI, 16 * dt, g, r, s[0][kt], s[NTL - 1][kt]);
+                tmf::mma_frames<NTL>(dkk, Qimg, LDI, 16 * dt, g, r, dp[0][kt], dp[NTL - 1][kt]);
+                if (key < F) {
+                    float a[4] = {dkk[0], dkk[1], dkk[2], dkk[3]}, bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
+                    store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
+                    store4(dvp + (long)key * sv + 16 * dt + 4 * g, bb);
+                }
             }
         }
     }

@@ -37,6 +37,13 @@ int istvt_rows_reduce_add(const float* ws, int rows, int nacc, int N, float* o0,
     return istvt_check_launch();
 }
 
+// the same through the C ABI: out[i] += sum_{r < rows} ws[r * n + i] in row order (any n; istvt_splitk_reduce is the
+// 16-byte-vector form for n % 4 == 0)
+extern "C" int istvt_rows_reduce(const float* ws, int rows, long n, float* out, hipStream_t stream) {
+    if (!ws || !out || n <= 0 || n > 0x7fffffffL) return ISTVT_ERR_SHAPE;
+    return istvt_rows_reduce_add(ws, rows, 1, (int)n, out, nullptr, nullptr, stream);
+}
+
 // ------------------------------------------------------------------------------------------
 // out[n] += sum_m x[m][n]   (bias gradient of a Linear: colsum of dY).  fp32 accumulate.  Thread owns 8 consecutive
 // columns; 4 waves split the rows of a row block; every row block stores ONE partial row (ws[row block][N]) and

@@ -250,7 +250,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) Mma<T>::mma(acc[mt][nt], bf[nt], af[mt]);
+                for (int nt = 0; nt < 4; ++nt) {
+                    if constexpr (sizeof(T) == 4) {
+                        // float32 parity mode: every 32-deep step is summed from zero and then added to the running
+                        // total (blocked summation).  One sequential fp32 FMA chain over K = 728 ... 2912 -- what eight
+                        // v_mfma_f32_16x16x4_f32 per step on ONE accumulator amount to -- left the gradients of the golden
+                        // model G5 6-8x further from the float64 reference run than torch's CPU float32 (whose GEMM keeps
+                        // 8-16 partial sums); the error now grows with 32 + K / 32 terms instead of K.
+                        f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+                        Mma<T>::mma(part, bf[nt], af[mt]);
+                        acc[mt][nt] += part;
+                    } else {
+                        Mma<T>::mma(acc[mt][nt], bf[nt], af[mt]);
+                    }
+                }
         }
         __syncthreads();
         if (more) {

@@ -247,10 +247,10 @@ extern "C" int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, 
 }
 
 // Workgroups of the backward launch for M rows = rows of the partial-sum workspace per accumulator.  Measured at C2
-// (35 launches per step) with the old per-workgroup atomics tail: 256 -> 2.95 ms, 512 -> 2.83, 1024 -> 3.28; with
-// partial rows the tail is gone and the count only trades latency hiding against the 3 x D floats each one stores.
+// (M = 56 736, bf16, with the residual input; tools/ln_bench.py): 256 -> 94.8 us, 512 -> 66.3, 1024 -> 74.1, 2048 -> 72.7
+// (the atomics version of round 2: 65.6 at 512).
 static long ln_bwd_blocks(long M) {
-    static const long cap = istvt_tune("ISTVT_LN_BWD_BLOCKS", 1024);
+    static const long cap = istvt_tune("ISTVT_LN_BWD_BLOCKS", 512);
     long blocks = (M + 3) / 4;
     if (blocks > cap) blocks = cap;
     return blocks < 1 ? 1 : blocks;

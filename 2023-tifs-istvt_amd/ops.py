@@ -416,7 +416,8 @@ def _pick_splitk(out_rows: int, out_cols: int, red: int, big_tiles: bool = False
 
 
 def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """out[N,K] (+)= dy.T @ x   (dy [M,N], x [M,K]); fp32 accumulate via split-K atomics."""
+    """out[N,K] (+)= dy.T @ x   (dy [M,N], x [M,K]); fp32 accumulate; the reduction dimension is split over workgroups
+    that write fp32 partial slabs, summed in split order by one reduce pass (no atomics: bit-reproducible)."""
     M, N = dy.shape
     K = x.shape[1]
     (dy, ldy), (x, ldx) = rows(dy), rows(x)
@@ -434,8 +435,19 @@ def linear_wgrad(dy: Tensor, x: Tensor, out: Optional[Tensor] = None) -> Tensor:
         gemm_raw(dy, ldy, False, x, ldx, False, ws, K, N, K, M, out_mode=3, splitk=splits)
         _lib.check(_lib.lib().istvt_splitk_reduce(ws.data_ptr(), splits, N * K, out.data_ptr(), _stream()),
                    'istvt_splitk_reduce')
+    elif splits > 1:
+        bk = 64 if dy.dtype == torch.bfloat16 else 32
+        kper = -(-(-(-M // splits)) // bk) * bk            # what the C side derives: ceil(ceil(M/s)/bk)*bk
+        splits = -(-M // kper)
+        ws = torch.empty((splits, N, K), dtype=torch.float32, device=dy.device)
+        gemm_raw(dy, ldy, False, x, ldx, False, ws, K, N, K, M, out_mode=3, splitk=splits)
+        if (N * K) % 4 == 0:
+            _lib.check(_lib.lib().istvt_splitk_reduce(ws.data_ptr(), splits, N * K, out.data_ptr(), _stream()),
+                       'istvt_splitk_reduce')
+        else:
+            _lib.check(_lib.lib().istvt_rows_reduce(ws.data_ptr(), splits, N * K, out.data_ptr(), _stream()), 'istvt_rows_reduce')
     else:
-        gemm_raw(dy, ldy, False, x, ldx, False, out, K, N, K, M, out_mode=2, splitk=splits)
+        gemm_raw(dy, ldy, False, x, ldx, False, out, K, N, K, M, out_mode=2, splitk=1)       # one writer per element
     return out
 
 

@@ -65,10 +65,22 @@ def parse():
                     help='skip the extra K steps that fill the with_dead_row_elimination field (profiled runs: one kind of step in the trace)')
     ap.add_argument('--no-wgrad-overlap', action='store_true',
                     help='weight-gradient GEMMs on the main stream (as in the instrumented step) instead of the side stream')
+    ap.add_argument('--config', default=None, choices=['C1', 'C2', 'C3', 'C4', 'C5'],
+                    help='a BASELINE.json configuration by name: C1 1-clip T=4 96^2 depth-2 float32, C2 (default) B=32 T=8 224^2 bf16, '
+                         'C3 = C2 per GPU on 8 GPUs (use with --gpus 8), C4 T=16, C5 B=64 with fp8 spatial-attention operands')
+    ap.add_argument('--host-boundary', action='store_true',
+                    help='extra field with_host_boundary: the same K steps with the reference loop\'s host side in the timed '
+                         'region (train_CNN.py:506,512,534-536): per-step H2D copy of the (B,T,3,S,S) batch from pinned memory '
+                         '(double-buffered on a copy stream), loss.item() and the accuracy count; NOT the headline value')
     ap.add_argument('--plumbing-only', action='store_true',
                     help='exercise only the launch / process-group / timing / JSON plumbing (no model, no GPU needed): '
                          'what the CPU test of the self-launching --gpus N path runs')
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = {'C1': dict(batch=1, frames=4, size=96, depth=2, dtype='f32'), 'C2': {}, 'C3': {},
+              'C4': dict(frames=16), 'C5': dict(batch=64, attn_fp8=True)}.get(a.config, {})
+    for k, v in preset.items():
+        setattr(a, k, v)
+    return a
 
 
 def self_launch(a):
@@ -239,21 +251,23 @@ def main():
     if a.dead_row_elimination:
         model.set_dead_row_elimination(True)
 
-    def step(reduce=True):
+    def step(reduce=True, xin=None, lab=None, want_logits=False):
+        xin = x if xin is None else xin
+        lab = labels if lab is None else lab
         if a.eval:
             with torch.no_grad():
-                return model(x).sum()
+                return model(xin).sum()
         if a.torch_optimizer:
             bucket.zero()
         else:
             opt.zero_grad()                 # a pass only before the first step: the fused step re-zeroes the gradients
-        logits = model(x)
-        loss = crit(logits.view(-1), labels)
+        logits = model(xin)
+        loss = crit(logits.view(-1), lab)
         loss.backward()
         if reduce:
             bucket.all_reduce()
         opt.step()
-        return loss
+        return (loss, logits) if want_logits else loss
 
     def sync():
         if world > 1:
@@ -303,6 +317,50 @@ def main():
                'note': 'opt-in STTransformer.dead_row_elimination: last-layer rows that cannot reach the logits skipped, '
                        'results identical; NOT the headline value'}
         model.set_dead_row_elimination(False)
+
+    # ---- extra field: the reference loop's host boundary inside the timed region (train_CNN.py:506,512,534-536)
+    hostb = None
+    if a.host_boundary and not a.eval:
+        shape = (a.batch, a.frames, 3, a.size, a.size)
+        pin = [torch.randn(shape, generator=g).pin_memory() for _ in range(2)]
+        pin_l = [(torch.rand((a.batch,), generator=g) > 0.5).float().pin_memory() for _ in range(2)]
+        dbuf = [torch.empty(shape, device=dev) for _ in range(2)]
+        dlab = [torch.empty((a.batch,), device=dev) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(i):                      # image.cuda() / labels.cuda() of the NEXT batch, under the current step's kernels
+            with torch.cuda.stream(copy_stream):
+                dbuf[i % 2].copy_(pin[i % 2], non_blocking=True)
+                dlab[i % 2].copy_(pin_l[i % 2], non_blocking=True)
+                ready[i % 2].record(copy_stream)
+
+        def hb_steps(n):
+            correct, running = 0, 0.0
+            upload(0)
+            for i in range(n):
+                torch.cuda.current_stream(dev).wait_event(ready[i % 2])
+                if i + 1 < n:
+                    upload(i + 1)           # its buffer was last read by step i - 1, which the .item() below has waited for
+                loss_i, logits_i = step(xin=dbuf[i % 2], lab=dlab[i % 2], want_logits=True)
+                preds = (logits_i.view(-1) > 0).float()
+                running += loss_i.item()                              # the per-step device -> host sync of the reference
+                correct += int(torch.sum(preds == dlab[i % 2]).item())
+            return correct, running
+        hb_steps(2)
+        sync()
+        t1 = time.perf_counter()
+        hb_steps(a.steps)
+        sync()
+        e3 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e3 = float(t.item())
+        hostb = {'ms_per_step': round(e3 / a.steps * 1e3, 3), 'clips_per_s': round(world * a.batch * a.steps / e3, 3),
+                 'h2d_MB_per_step': round(a.batch * a.frames * 3 * a.size * a.size * 4 / 1e6, 1),
+                 'note': 'per step: pinned-memory H2D copy of the next batch on a copy stream (hidden under the current '
+                         'step), loss.item() and the accuracy count (train_CNN.py:506,512,534-536); NOT the headline value'}
 
     # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
     roof = None
@@ -366,10 +424,24 @@ def main():
         is_c2 = (a.batch, a.frames, a.size, a.depth, a.dtype) == (32, 8, 224, 12, 'bf16')
         if is_c2 and pmc:
             table = json.load(open(pmc))
-            rec = table.get('void ' + dom + '(GemmArgs)') or table.get(dom + '(GemmArgs)') or table.get('void ' + dom)
-            if rec and 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
+
+            def rec_of(kname):
+                return table.get('void ' + kname + '(GemmArgs)') or table.get(kname + '(GemmArgs)') or table.get('void ' + kname) \
+                    or table.get(kname)
+            # the committed counters describe THIS code only if every GEMM kernel that just ran is in them with the same
+            # launches per step; otherwise the file is stale (another kernel mix) and no traffic figure is printed
+            stale = [k for k, v in by.items() if k.startswith('gemm256')
+                     and (rec_of(k) is None or rec_of(k).get('FETCH_SIZE', {}).get('launches_per_step', v[2]) != v[2])]
+            rec = rec_of(dom)
+            if not stale and rec and 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
                 roof['traffic'] = round((2.0 * rec['FETCH_SIZE']['avg_KB'] + rec['WRITE_SIZE']['avg_KB']) * 1024)
                 roof['traffic_unit'] = 'bytes/launch (rocprofv3 --pmc, profiles/pmc/%s)' % os.path.basename(pmc)
+                if 'mfma_busy_frac' in rec:
+                    roof['mfma_busy_frac'] = rec['mfma_busy_frac']
+                    roof['mfma_busy_note'] = 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 4 SIMDs x 256 CUs), same PMC file'
+            else:
+                roof['traffic_note'] = 'profiles/pmc/%s does not match the kernels of this run (%s): not reported' % (
+                    os.path.basename(pmc), ', '.join(stale) if stale else dom)
 
     if rank == 0:
         clips = world * a.batch * a.steps
@@ -401,6 +473,8 @@ def main():
         out['config']['dead_row_elimination'] = bool(a.dead_row_elimination)
         if dre:
             out['with_dead_row_elimination'] = dre
+        if hostb:
+            out['with_host_boundary'] = hostb
         if world > 1:
             out['distributed'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                   'per_rank_ms_per_step': per_rank,

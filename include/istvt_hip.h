@@ -258,6 +258,10 @@ int istvt_add(const void* a, long lda, const void* b, long ldb, void* out, long 
 int istvt_colsum(const void* x, float* out, long M, int N, long ld, float* ws, long ws_elems, int dtype,
                  istvt_stream_t stream);
 int istvt_colsum_ws_elems(long M, int N);
+/* out[i] += sum_{r < rows} ws[r * n + i], rows added in index order by one writer per element: the second stage of every
+ * per-column sum of this library (fp32 split-K slabs of narrow weight gradients, bias / token / BatchNorm-affine
+ * gradients) -- no floating-point atomics anywhere, so a training step is bit-reproducible */
+int istvt_rows_reduce(const float* ws, int rows, long n, float* out, istvt_stream_t stream);
 int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, istvt_stream_t stream);
 /* rows x cols cast between row-strided buffers (bf16 operand copies of fp32 weights with line-aligned rows) */
 int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtype, long ldo, long rows, int cols,

@@ -488,21 +488,25 @@ def test_depth12_fp32_and_bf16_vs_oracle():
     assert max(r[1] for r in rows) < 0.15, sorted(rows, key=lambda r: -r[1])[:5]
 
 
-def test_c2_full_step_bf16_bounded_by_fp32():
-    """ONE step of exactly what bench.py times (C2: B=32, T=8, 224^2, depth 12, bf16, fused bucket) against the same step
-    of the float32 HIP path (golden-pinned above): logits, loss and the flat gradient bucket."""
+@pytest.mark.parametrize('cfg', ['C2', 'C4', 'C5'])
+def test_full_size_step_bf16_bounded_by_fp32(cfg):
+    """ONE step of exactly what bench.py times, at FULL size, against the same step of the float32 HIP path (golden-pinned
+    above): logits, loss and the flat gradient bucket.  C2: B=32, T=8; C4 (BASELINE configs[3], `bench.py --config C4`):
+    B=32, T=16 (F = 17: the two-tile temporal kernels at production size); C5 (configs[4], `--config C5`): B=64 with fp8
+    (e4m3) operands in the spatial-attention MFMAs.  224^2, depth 12, bf16, fused bucket."""
     import istvt_pkg
     istvt_pkg.load()
     from istvt_amd import parallel
     XceptionVidTr, _ = _load()
-    B, T = 32, 8
+    B, T, fp8 = {'C2': (32, 8, False), 'C4': (32, 16, False), 'C5': (64, 8, True)}[cfg]
     g = torch.Generator().manual_seed(1)
     x = torch.randn((B, T, 3, 224, 224), generator=g).cuda()
     labels = (torch.rand((B,), generator=g) > 0.5).float().cuda()
     res = {}
     for dt in (torch.float32, torch.bfloat16):
         torch.manual_seed(0)
-        model = XceptionVidTr(num_frames=T, grid=14, depth=12, compute_dtype=dt).cuda().train()
+        model = XceptionVidTr(num_frames=T, grid=14, depth=12, compute_dtype=dt,
+                              attn_fp8=fp8 and dt == torch.bfloat16).cuda().train()
         live = [q for _, q in parallel.live_named_parameters(model)]
         bucket = parallel.GradBucket(live, fuse_accumulate=True)
         bucket.zero()
@@ -510,13 +514,14 @@ def test_c2_full_step_bf16_bounded_by_fp32():
         loss = torch.nn.BCEWithLogitsLoss()(logits.view(-1), labels)
         loss.backward()
         torch.cuda.synchronize()
+        assert torch.isfinite(logits).all() and torch.isfinite(bucket.flat).all()
         res[dt] = (logits.detach().float().cpu(), float(loss), bucket.flat.clone().cpu())
         del model, bucket, live, logits, loss
         torch.cuda.empty_cache()
     (y32, l32, g32), (y16, l16, g16) = res[torch.float32], res[torch.bfloat16]
     d = float((y16 - y32).abs().max())
     cos = float(torch.nn.functional.cosine_similarity(g16.double(), g32.double(), dim=0))
-    print('C2 step bf16 vs fp32: max |dlogit| %.4e (max |logit| %.3f), loss %.5f vs %.5f, bucket cosine %.5f, norm ratio %.4f'
+    print(cfg + ' step bf16 vs fp32: max |dlogit| %.4e (max |logit| %.3f), loss %.5f vs %.5f, bucket cosine %.5f, norm ratio %.4f'
           % (d, float(y32.abs().max()), l16, l32, cos, float(g16.norm() / g32.norm())))
     assert d <= BF16_LOGIT_TOL * max(1.0, float(y32.abs().max()))
     assert abs(l16 - l32) <= 1e-2 * max(1.0, l32)
