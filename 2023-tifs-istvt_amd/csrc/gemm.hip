@@ -35,6 +35,7 @@ struct GemmArgs {
     long slab;            // out_mode 3: blockIdx.z writes its fp32 partial at C + z * slab (elements)
     int gm;               // gemm256q: row-panels per tile group (L2 locality of the tile walk)
     int band;             // gemm256q: > 0: column bands of this many tiles instead (wide outputs, see tile_origin)
+    int blocked;          // float32 generic kernel: sum every 32-deep step from zero, then add it to the running total
     int walk;             // gemm256q: 0 = XCD-contiguous eighths of the (group, row, column) list, 1 = row-panel slab per XCD
     double* st_sum;       // gemm256q<.., STATS = 1>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
     double* st_sumsq;     //   (double[R][2][N] accumulators of stem.hip; train-mode BatchNorm statistics of a 1x1 conv)
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    if constexpr (sizeof(T) == 4) {
-                        // float32 parity mode: every 32-deep step is summed from zero and then added to the running
+                    if (sizeof(T) == 4 && p.blocked) {
+                        // float32 parity mode, flags & 1: every 32-deep step is summed from zero and then added to the running
                         // total (blocked summation).  One sequential fp32 FMA chain over K = 728 ... 2912 -- what eight
                         // v_mfma_f32_16x16x4_f32 per step on ONE accumulator amount to -- left the gradients of the golden
                         // model G5 6-8x further from the float64 reference run than torch's CPU float32 (whose GEMM keeps
@@ -301,7 +302,7 @@ static int launch_gemm(const GemmArgs& a, int a_kc, int b_kc, int splitk, hipStr
 
 extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc,
                           int M, int N, int K, const float* bias, const void* residual, long ldr, void* C2, int epi,
-                          int out_mode, int splitk, float alpha, double* col_sum, double* col_sumsq, int dtype,
+                          int out_mode, int splitk, float alpha, double* col_sum, double* col_sumsq, int flags, int dtype,
                           hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return ISTVT_ERR_SHAPE;
     if (out_mode < 0 || out_mode > 3 || epi < 0 || epi > 2) return ISTVT_ERR_SHAPE;
@@ -315,6 +316,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.out_f32 = (out_mode == 1 || out_mode == 3); a.atomic_f32 = out_mode == 2; a.alpha = alpha;
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
     a.st_sum = col_sum; a.st_sumsq = col_sumsq;
+    a.blocked = flags & 1;
     if (col_sumsq && !col_sum) return ISTVT_ERR_SHAPE;
     a.gm = 4;             // sweep at the model's shapes: 4 row-panels per tile group is best or neutral everywhere
     {

@@ -268,11 +268,14 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
              C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0,
-             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None):
+             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None, blocked: bool = True):
     """stats: double [R][2][N] accumulator (stem.new_stats): the kernel adds the column sums / sums of squares of the
     stored outputs (fused train-mode BatchNorm statistics); only legal where stats_fusable() says so.
     csum=True (with stats, epi 2 only): only the column sums are accumulated (a bias gradient; the caller folds them
-    with istvt_stats_reduce_add)."""
+    with istvt_stats_reduce_add).
+    blocked (float32 only): blocked summation over the reduction dimension (istvt_gemm flags bit 0).  False = one
+    sequential fp32 chain, which the Xception stem's forward / input-gradient convolutions keep (it reproduces the
+    reference CPU run's ReLU / arg-max decisions)."""
     _req(A); _req(B); _req(C)
     if A.dtype != B.dtype:
         raise TypeError('gemm operands must share a dtype (%s vs %s)' % (A.dtype, B.dtype))
@@ -285,7 +288,8 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     rc = _lib.lib().istvt_gemm(A.data_ptr(), lda, int(a_kc), B.data_ptr(), ldb, int(b_kc), C.data_ptr(), ldc, M, N, K,
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
                                stats[0, 0].data_ptr() if stats is not None else None,
-                               stats[0, 1].data_ptr() if (stats is not None and csum is None) else None, dtype_code(A), _stream())
+                               stats[0, 1].data_ptr() if (stats is not None and csum is None) else None, int(bool(blocked)),
+                               dtype_code(A), _stream())
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (bool(a_kc), bool(b_kc)), (M, N, K),
@@ -307,7 +311,7 @@ def stats_fusable(x: Tensor, w: Tensor) -> bool:
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               gelu: bool = False, pad: bool = False, stats: Optional[Tensor] = None):
+               gelu: bool = False, pad: bool = False, stats: Optional[Tensor] = None, blocked: bool = True):
     """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype); both may
     be row-strided views.  pad=True: the outputs are [M, N] views with line-aligned rows.  stats: see gemm_raw."""
     M, K = x.shape
@@ -320,12 +324,12 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Op
     ldc = y.stride(0) if M > 1 else N
     if gelu:
         g = empty_rows(M, N, x.dtype, x.device, pad)
-        gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, C2=g, epi=1)
+        gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, C2=g, epi=1, blocked=blocked)
         return y, g
     ldr = 0
     if residual is not None:
         residual, ldr = rows(residual)
-    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr, stats=stats)
+    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr, stats=stats, blocked=blocked)
     return y
 
 
@@ -359,7 +363,7 @@ def _transposed_operand(w: Tensor) -> Tensor:
 
 
 def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Optional[Tensor] = None,
-                 pad: bool = False, csum: Optional[Tensor] = None) -> Tensor:
+                 pad: bool = False, csum: Optional[Tensor] = None, blocked: bool = True) -> Tensor:
     """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u).
     wt = w^T [K,N] (optional): use the k-contiguous kernel instead of the transposed-operand one.
     csum (with gelu_u): float32 [K] += column sums of dx, taken in the GEMM's epilogue where the kernel supports it
@@ -390,12 +394,12 @@ def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Opt
             gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, stats=acc, csum=True)
             _lib.check(_lib.lib().istvt_stats_reduce_add(acc.data_ptr(), K, csum.data_ptr(), _stream()), 'istvt_stats_reduce_add')
         else:
-            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi)
+            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, blocked=blocked)
             if csum is not None:
                 colsum(dx, out=csum)
     else:
         w, ldb = rows(w)
-        gemm_raw(dy, lda, True, w, ldb, False, dx, ldc, M, K, N, C2=c2, epi=epi)
+        gemm_raw(dy, lda, True, w, ldb, False, dx, ldc, M, K, N, C2=c2, epi=epi, blocked=blocked)
         if csum is not None:
             colsum(dx, out=csum)
     return dx

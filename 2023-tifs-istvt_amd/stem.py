@@ -96,9 +96,9 @@ def pointwise_bn(x: Tensor, w: Tensor, M: int, C: int, gamma: Tensor, beta: Tens
     acc = None
     if training and ops.stats_fusable(x, w):
         acc = new_stats(C, x.device)
-        u = ops.linear_fwd(x, w, stats=acc)
+        u = ops.linear_fwd(x, w, stats=acc, blocked=False)
     else:
-        u = ops.linear_fwd(x, w)
+        u = ops.linear_fwd(x, w, blocked=False)
     return u, bn_forward_stats(u, M, C, gamma, beta, rmean, rvar, training, acc=acc)
 
 
@@ -249,7 +249,7 @@ class StemFn(Function):
             # summation order flips ReLU masks at |z| ~ 1e-7 and moves early-layer gradients by 1e-2
             col1 = torch.empty((M1, 32), dtype=dtype, device=dev)
             _lib.check(L.istvt_im2col_conv1(x.data_ptr(), col1.data_ptr(), Fr, S, ops._DT[dtype], _stream()), 'istvt_im2col_conv1')
-            u1 = ops.linear_fwd(col1, w1)
+            u1 = ops.linear_fwd(col1, w1, blocked=False)
             del col1
         bn1 = bn('bn1', u1, M1, 32)
         # conv2 (32->64, 3x3, p0): im2col applies bn1 + ReLU on load
@@ -264,7 +264,7 @@ class StemFn(Function):
             col2 = torch.empty((M2, 288), dtype=dtype, device=dev)
             _lib.check(L.istvt_im2col3x3(u1.data_ptr(), bn1.ptr(), 1, col2.data_ptr(), Fr, H1, H1, 32, ops._DT[dtype], _stream()),
                        'istvt_im2col3x3')
-            u2 = ops.linear_fwd(col2, w2)
+            u2 = ops.linear_fwd(col2, w2, blocked=False)
             del col2
         bn2 = bn('bn2', u2, M2, 64)
         a2 = bn_apply(u2, bn2, M2, 64, True)
@@ -357,7 +357,7 @@ class StemFn(Function):
             # skip path: skipbn -> 1x1 stride-2 conv
             duS = bn_bwd(dOut, blk['uS'], blk['bnS'], name + '.skipbn', Ms, cout)
             lin_wgrad(name + '.skip.weight', duS, blk['xs'])
-            dxs = ops.linear_dgrad(duS, blk['wsk'])
+            dxs = ops.linear_dgrad(duS, blk['wsk'], blocked=False)
             # rep path: maxpool -> BN_B -> pointwise_B -> depthwise_B -> ReLU -> BN_A -> pointwise_A -> depthwise_A
             dzB = torch.empty((M, cout), dtype=dtype, device=dev)
             # the BatchNorm-backward sums of BN_B are taken by the pooling backward as it writes dz (train mode)
@@ -372,7 +372,7 @@ class StemFn(Function):
             del dzB
             sB = '%s.rep.%d' % (name, i0 + 3)
             lin_wgrad(sB + '.pointwise.weight', duB, blk['d2'])
-            dd2 = ops.linear_dgrad(duB, blk['wpwB'])
+            dd2 = ops.linear_dgrad(duB, blk['wpwB'], blocked=False)
             del duB
             dw_wgrad(sB + '.conv1.weight', blk['uA'], dd2, H, cout, blk['bnA'], True)
             statsA = new_stats(cout, dev)
@@ -384,7 +384,7 @@ class StemFn(Function):
             del dzA
             sA = '%s.rep.%d' % (name, i0)
             lin_wgrad(sA + '.pointwise.weight', duA, blk['d1'])
-            dd1 = ops.linear_dgrad(duA, blk['wpwA'])
+            dd1 = ops.linear_dgrad(duA, blk['wpwA'], blocked=False)
             del duA
             dw_wgrad(sA + '.conv1.weight', blk['X'], dd1, H, cin, None, blk['pre_relu'])
             if blk['pre_relu']:
@@ -415,7 +415,7 @@ class StemFn(Function):
             _lib.check(L.istvt_im2col3x3(sv['u1'].data_ptr(), sv['bn1'].ptr(), 1, col2.data_ptr(), Fr, H1, H1, 32, dtc, _stream()),
                        'istvt_im2col3x3')
             dW2 = ops.linear_wgrad(du2, col2)                                    # [64][(dy,dx,ci)]
-            dcol2 = ops.linear_dgrad(du2, sv['w2'])
+            dcol2 = ops.linear_dgrad(du2, sv['w2'], blocked=False)
             del du2, col2
             _lib.check(L.istvt_col2im3x3(dcol2.data_ptr(), sv['u1'].data_ptr(), sv['bn1'].ptr(), dz1.data_ptr(), Fr, H1, H1, 32,
                                          dtc, _stream()),
@@ -440,7 +440,7 @@ class StemFn(Function):
             del col1
         dx = None
         if ctx.need_dx:
-            dcol1 = ops.linear_dgrad(du1, sv['w1'])
+            dcol1 = ops.linear_dgrad(du1, sv['w1'], blocked=False)
             dx = torch.empty_like(sv['x'])
             _lib.check(L.istvt_col2im_conv1(dcol1.data_ptr(), dx.data_ptr(), Fr, S, dtc, _stream()), 'istvt_col2im_conv1')
         ctx.sv = None

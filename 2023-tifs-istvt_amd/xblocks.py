@@ -63,7 +63,7 @@ class SepConvFn(Function):
         w9 = _tap_major(wdw)
         wp = ops.weight_as(wpw, x.dtype)
         d = dwconv(x, w9, Fr, H, W, cin)
-        u = ops.linear_fwd(d, wp)
+        u = ops.linear_fwd(d, wp, blocked=False)
         ctx.save_for_backward(x, d, wdw, wpw)
         ctx.geom = (Fr, H, W, cin, cout)
         return u
@@ -75,7 +75,7 @@ class SepConvFn(Function):
         Fr, H, W, cin, cout = ctx.geom
         du = _c(du)
         wp = ops.weight_as(wpw, du.dtype)
-        dd = ops.linear_dgrad(du, wp)
+        dd = ops.linear_dgrad(du, wp, blocked=False)
         t = _fused_target(wpw, (cout, cin))
         gpw = ops.linear_wgrad(du, d, out=t)
         t2 = _fused_target(wdw, (cin, 9))
@@ -201,7 +201,7 @@ class RepChainFn(Function):
             duS = bn_bwd(dout, sk['uS'], sk['bnS'], 4 * nu + 1, Ms, spec.cout)
             lin_wgrad(4 * nu, duS, sk['xs'])
             if ctx.need_dx:
-                dskip = ops.linear_dgrad(duS, sk['ws'])
+                dskip = ops.linear_dgrad(duS, sk['ws'], blocked=False)
                 skip_full = spec.tail != 'pool'
         elif spec.tail == 'add':
             dskip, skip_full = dout, True
@@ -225,7 +225,7 @@ class RepChainFn(Function):
             du = bn_bwd(dz, un['u'], un['bn'], 4 * i + 2, M, cout, stats=stats)
             del dz
             lin_wgrad(4 * i + 1, du, un['d'])
-            dd = ops.linear_dgrad(du, un['wp'])
+            dd = ops.linear_dgrad(du, un['wp'], blocked=False)
             del du
             q = params[4 * i]
             t = _fused_target(q, (cin, 9))

@@ -54,10 +54,15 @@ typedef void* istvt_stream_t; /* hipStream_t */
  *           second pass.  Only the persistent bf16 NT kernel does this (forward of a >= 64-wide, 16-byte aligned
  *           problem with epi 0, no residual, out_mode 0); any other combination returns -3.
  *           col_sum alone (col_sumsq NULL) with epi 2: only the column sums -- the bias gradient of FeedForward's hidden
- *           layer (module.py:27), whose dy is exactly this GEMM's output; fold with istvt_stats_reduce_add. */
+ *           layer (module.py:27), whose dy is exactly this GEMM's output; fold with istvt_stats_reduce_add.
+ * flags:    bit 0 (float32 only): blocked summation -- every 32-deep step of the reduction is summed from zero and added
+ *           to the running total, so the rounding error grows with 32 + K/32 terms instead of K (the transformer's
+ *           Linears and every weight gradient use it: 10x closer to the float64 reference run on golden G5).  0 = one
+ *           sequential fp32 FMA chain: the order that reproduces the reference CPU convolutions' ReLU / arg-max
+ *           decisions in the Xception stem (forward and input gradient of its convolutions). */
 int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
                int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
-               float alpha, double* col_sum, double* col_sumsq, int dtype, istvt_stream_t stream);
+               float alpha, double* col_sum, double* col_sumsq, int flags, int dtype, istvt_stream_t stream);
 
 /* out[i] += sum_z ws[z*n + i]: second pass of a split-K weight gradient written as partial slabs */
 int istvt_splitk_reduce(const float* ws, int splits, long n, float* out, istvt_stream_t stream);

@@ -64,35 +64,38 @@ def test_g5_native_end_to_end_hip(golden_dir):
     got = sorted(k for k, p in named.items() if p.grad is not None)
     assert got == sorted(live)                        # the 19.7 M dead Xception params get no gradient
     # Gradient criterion, per tensor, against the FLOAT64 run of the reference (golden G5b):
-    #     |hip - ref64|  <=  10 * |ref32 - ref64|  +  2e-3 * |ref64|  +  2e-6 * gmax
-    # i.e. the HIP float32 path may be off the float64 truth by at most ten times what the reference's own float32 run
+    #     |hip - ref64|  <=  3 * |ref32 - ref64|  +  2e-3 * |ref64|  +  2e-6 * gmax
+    # i.e. the HIP float32 path may be off the float64 truth by at most three times what the reference's own float32 run
     # is off it, plus a floor for tensors whose reference error happens to be ~0 and an absolute floor for the to_qk
     # gradients of saturated temporal softmaxes (7 orders below the rest, at the float32 noise floor of p * (dp - delta):
     # the reference's own float32 value of layers.6.0.fn.to_qk.weight is 7 % off its float64 value).
-    # Measured (tools/g5_diag.py): the HIP float32 gradients are 6-8x less accurate than torch's CPU float32 ones on this
-    # recipe model -- median norm error 0.37 % against 0.06 %, forward logit 1.2e-5 against 1.7e-6 -- because the parity-mode
-    # GEMM accumulates K = 728 ... 2912 as ONE sequential float32 FMA chain per output (v_mfma_f32_16x16x4_f32) where
-    # MKL keeps 8-16 partial sums; the recipe's saturated softmaxes and BatchNorm chain amplify both.  The worst tensor
-    # (layers.5.0.fn.to_qk.weight) moves by ~1 % from run to run with the order of the float atomics upstream.
+    # Round 2 needed k = 10: the parity-mode GEMM accumulated K = 728 ... 2912 (and the M = 15 204 rows of a weight
+    # gradient) as ONE sequential float32 FMA chain per output where MKL keeps 8-16 partial sums, and float atomics
+    # moved the worst tensor by ~1 % from run to run.  Now: blocked summation in the float32 GEMM (istvt_gemm flags bit 0)
+    # for the transformer's Linears and every weight gradient, and fixed-order reductions everywhere -- measured worst ratio
+    # 0.86 at k = 3, median norm error 2.1e-3 (round 2: 3.7e-3), identical bits on every run
+    # (test_training_step_is_bit_reproducible).  The stem's forward / input-gradient convolutions keep the sequential order:
+    # it reproduces the reference CPU run's ReLU / arg-max decisions (goldens G1 / G1b to 1e-5; blocked summation there moved
+    # the G1 gradient norms by 1e-2 through a handful of flipped decisions, while the G5 median dropped to 3.3e-4).
     g64 = np.load(os.path.join(golden_dir, 'G5b_native_fp64.npz'))
     assert relerr(logits, g64['logits64']) < 1e-3
     gmax = max(float(g64['gnorm64.' + k]) for k in live)
     rows = []
     for k in live:
         got, r32, r64 = float(named[k].grad.norm()), float(g['gnorm.' + k]), float(g64['gnorm64.' + k])
-        bound = 10.0 * abs(r32 - r64) + 2e-3 * r64 + 2e-6 * gmax
+        bound = 3.0 * abs(r32 - r64) + 2e-3 * r64 + 2e-6 * gmax
         rows.append((abs(got - r64) / bound, k, got, r32, r64))
     rows.sort(reverse=True)
-    print('G5 worst |hip - ref64| / (10 |ref32 - ref64| + 2e-3 |ref64| + 2e-6 gmax):', rows[:6])
+    print('G5 worst |hip - ref64| / (3 |ref32 - ref64| + 2e-3 |ref64| + 2e-6 gmax):', rows[:6])
     assert rows[0][0] <= 1.0, rows[:6]
     med = sorted(abs(r[2] / r[4] - 1.0) for r in rows)[len(rows) // 2]
     print('G5 median |hip / ref64 - 1| of the gradient norms: %.3e' % med)
-    assert med < 1e-2
+    assert med < 4e-3         # measured 2.1e-3 (3.3e-4 with blocked summation in the stem too, which the G1 goldens forbid: see stem.py)
     for k in g.files:
         if k.startswith('grad.'):          # 64-entry slices, same criterion in norm
             got_s = named[k[5:]].grad.reshape(-1)[:64].double().cpu()
             r32, r64 = torch.from_numpy(g[k]).double(), torch.from_numpy(g64['grad64.' + k[5:]]).double()
-            assert float((got_s - r64).norm()) <= 10.0 * float((r32 - r64).norm()) + 2e-3 * float(r64.norm()) + 2e-7 * gmax, k
+            assert float((got_s - r64).norm()) <= 3.0 * float((r32 - r64).norm()) + 2e-3 * float(r64.norm()) + 2e-7 * gmax, k
     opt.step()
     for k in g.files:
         if k.startswith('after_sgd.'):
