@@ -63,6 +63,7 @@ SIGNATURES = {
     'istvt_cast': [P, I, P, I, L, P],
     'istvt_cast2d': [P, I, L, P, I, L, L, I, P],
     'istvt_cast_transpose': [P, L, P, L, P, L, I, I, P],
+    'istvt_cast_transpose_group': [I, P, P, P, P, P, P, P, P, P],
     'istvt_relu_avgpool_fwd': [P, P, I, I, I, I, I, P],
     'istvt_relu_avgpool_bwd': [P, P, P, I, I, I, I, I, P],
     'istvt_prepend_fwd': [P, P, P, P, L, L, I, I, I, I, I, P],

@@ -344,6 +344,86 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// The same for up to ISTVT_CAST_GROUP_MAX weights in ONE launch: the 84 per-weight launches of a training step (one per
+// nn.Linear weight whose fp32 master copy the optimizer has just changed) are each far below the ~5 us a launch occupies
+// the queue for (0.45 ms per step at C2); grouped they are a handful.  Workgroup b belongs to the problem whose
+// start[] range holds it; inside the problem the tile order is that of cast_transpose_kernel.
+constexpr int ISTVT_CAST_GROUP_MAX = 32;
+struct CastGroupArgs {
+    const float* in[ISTVT_CAST_GROUP_MAX];
+    bf16_t* out[ISTVT_CAST_GROUP_MAX];
+    bf16_t* outT[ISTVT_CAST_GROUP_MAX];
+    long ldi[ISTVT_CAST_GROUP_MAX], ldo[ISTVT_CAST_GROUP_MAX], ldt[ISTVT_CAST_GROUP_MAX];
+    int R[ISTVT_CAST_GROUP_MAX], C[ISTVT_CAST_GROUP_MAX];
+    int start[ISTVT_CAST_GROUP_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void cast_transpose_group_kernel(CastGroupArgs g) {
+    __shared__ float tile[64][65];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < ISTVT_CAST_GROUP_MAX; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.start[i]) pi = i;
+    const float* __restrict__ in = g.in[pi];
+    bf16_t* __restrict__ out = g.out[pi];
+    bf16_t* __restrict__ outT = g.outT[pi];
+    const long ldi = g.ldi[pi], ldo = g.ldo[pi], ldt = g.ldt[pi];
+    const int R = g.R[pi], C = g.C[pi];
+    const int b = (int)blockIdx.x - g.start[pi], tx = (C + 63) / 64;
+    const int r0 = (b / tx) * 64, c0 = (b % tx) * 64;
+    const int row = threadIdx.x >> 2, cc = (threadIdx.x & 3) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = c0 + cc + 8 * h;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool ok = r0 + row < R && col < C;
+        if (ok) load8(in + (long)(r0 + row) * ldi + col, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[row][cc + 8 * h + j] = v[j];
+        if (ok) store8(out + (long)(r0 + row) * ldo + col, v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int tr = c0 + row;
+        const int tc = r0 + cc + 8 * h;
+        if (tr < C && tc < R) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[cc + 8 * h + j][row];
+            store8(outT + (long)tr * ldt + tc, v);
+        }
+    }
+}
+
+// in[i] float [R_i][C_i] (row stride ldi_i) -> out[i] bf16 [R_i][C_i] (ldo_i) and outT[i] bf16 [C_i][R_i] (ldt_i), i < count
+// (any count: launched in groups of 32)
+extern "C" int istvt_cast_transpose_group(int count, const float* const* in, const long* ldi, void* const* out,
+                                          const long* ldo, void* const* outT, const long* ldt, const int* R, const int* C,
+                                          hipStream_t stream) {
+    if (count < 1) return ISTVT_ERR_SHAPE;
+    for (int i = 0; i < count; ++i)
+        if (R[i] <= 0 || C[i] <= 0 || R[i] % 8 || C[i] % 8 || ldi[i] < C[i] || ldo[i] < C[i] || ldt[i] < R[i] || ldi[i] % 4 ||
+            ldo[i] % 8 || ldt[i] % 8 || !in[i] || !out[i] || !outT[i]) return ISTVT_ERR_SHAPE;
+    for (int i0 = 0; i0 < count; i0 += ISTVT_CAST_GROUP_MAX) {
+        CastGroupArgs g;
+        g.count = count - i0 < ISTVT_CAST_GROUP_MAX ? count - i0 : ISTVT_CAST_GROUP_MAX;
+        int start = 0;
+        for (int j = 0; j < ISTVT_CAST_GROUP_MAX; ++j) {
+            const int i = i0 + (j < g.count ? j : 0);
+            g.in[j] = in[i]; g.out[j] = (bf16_t*)out[i]; g.outT[j] = (bf16_t*)outT[i];
+            g.ldi[j] = ldi[i]; g.ldo[j] = ldo[i]; g.ldt[j] = ldt[i]; g.R[j] = R[i]; g.C[j] = C[i];
+            g.start[j] = start;
+            if (j < g.count) start += ((C[i] + 63) / 64) * ((R[i] + 63) / 64);
+        }
+        g.start[ISTVT_CAST_GROUP_MAX] = start;
+        hipLaunchKernelGGL(cast_transpose_group_kernel, dim3(start), dim3(256), 0, stream, g);
+        const int rc = istvt_check_launch();
+        if (rc) return rc;
+    }
+    return ISTVT_OK;
+}
+
 extern "C" int istvt_cast_transpose(const float* in, long ldi, void* out, long ldo, void* outT, long ldt, int R, int C,
                                     hipStream_t stream) {
     if (R <= 0 || C <= 0 || R % 8 || C % 8 || ldi < C || ldo < C || ldt < R || ldi % 4 || ldo % 8 || ldt % 8) return ISTVT_ERR_SHAPE;

@@ -29,6 +29,7 @@ class Transformer(nn.Module):
             ]))
 
     def forward(self, x):
+        ops.refresh_stale_operands()
         # both residual adds ride in the epilogue of the block's last GEMM; the residual's gradient is summed inside
         # the LayerNorm backward kernel (PreNorm residual='input')
         for attn, ff in self.layers:
@@ -57,6 +58,7 @@ class STTransformer(nn.Module):
             ]))
 
     def forward(self, x, hw=None, cls_of=None):
+        ops.refresh_stale_operands()     # every bf16 weight operand the optimizer step invalidated: ONE grouped cast launch
         # x = attn_s(attn_t(x)) + x ; x = ff(x) + x   (ONE residual around temporal-then-spatial,
         # vivit.py:99); both adds run in the epilogue of the block's last GEMM, and the residual's gradient is
         # summed inside the backward kernel of the LayerNorm that shares its input (PreNorm fork / 'input').

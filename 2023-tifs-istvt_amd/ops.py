@@ -107,6 +107,55 @@ def invalidate_weight_cache():
     """A kernel wrote parameters through raw pointers (no ``_version`` bump): drop every cached operand copy."""
     _wepoch[0] += 1
 
+
+# bf16 GEMM operands that come out of the fused cast + transpose pass (weight_as(pad=True) / weight_cat_as):
+# cache key -> (weakrefs of the fp32 parameters stacked in the operand, operand [sum R, C], transpose [C, sum R]).
+# refresh_stale_operands() re-casts every one whose parameters have changed in ONE grouped launch.
+_operands: dict = {}
+
+
+def _versions(ws) -> tuple:
+    return tuple(w._version for w in ws) + (_wepoch[0],)
+
+
+def refresh_stale_operands() -> int:
+    """Re-cast, in one grouped launch (istvt_cast_transpose_group), the bf16 operand copies (W and W^T) of every weight
+    that changed since they were made -- i.e. of all of them after an optimizer step.  The models call this at the start
+    of a forward pass; without it the same work happens lazily, one launch per weight (84 per step at depth 12, each far
+    shorter than the ~5 us a launch occupies the queue for).  Returns the number of weights re-cast."""
+    import ctypes as C
+    todo = []
+    for key, (refs, out, wt) in list(_operands.items()):
+        ws = [r() for r in refs]
+        hit = _wcache.get(key)
+        if any(w is None for w in ws) or hit is None or hit[2] is not out:
+            _operands.pop(key, None)
+            continue
+        ver = _versions(ws)
+        if hit[1] != ver:
+            todo.append((key, ws, out, wt, ver, hit))
+    if not todo:
+        return 0
+    srcs, ins, ldi, outs, ldo, outts, ldt, Rs, Cs = [], [], [], [], [], [], [], [], []
+    for key, ws, out, wt, ver, hit in todo:
+        es, r0 = out.element_size(), 0
+        for w in ws:
+            w2 = _c(w.detach().reshape(w.shape[0], -1))
+            srcs.append(w2)                       # kept alive until the launch is enqueued
+            n, K = w2.shape
+            ins.append(w2.data_ptr()); ldi.append(K)
+            outs.append(out.data_ptr() + r0 * out.stride(0) * es); ldo.append(out.stride(0))
+            outts.append(wt.data_ptr() + r0 * es); ldt.append(wt.stride(0))
+            Rs.append(n); Cs.append(K)
+            r0 += n
+    n = len(ins)
+    PA, LA, IA = C.c_void_p * n, C.c_long * n, C.c_int * n
+    _lib.check(_lib.lib().istvt_cast_transpose_group(n, PA(*ins), LA(*ldi), PA(*outs), LA(*ldo), PA(*outts), LA(*ldt),
+                                                     IA(*Rs), IA(*Cs), _stream()), 'istvt_cast_transpose_group')
+    for key, ws, out, wt, ver, hit in todo:
+        _wcache[key] = (hit[0], ver, out)
+    return n
+
 G256_MIN = 64          # smallest output edge routed to the 256x256 DMA GEMM (mirrors ISTVT_G256_MIN in gemm.hip)
 
 
@@ -134,7 +183,7 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
     pad = pad and w2.shape[1] % 8 == 0 and pad_ld(w2.shape[1]) != w2.shape[1]
     key = (id(w), 'p') if pad else id(w)    # id-keyed: Tensor.__eq__ is elementwise, so tensors cannot be dict keys
     hit = _wcache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == (w._version, _wepoch[0]) and hit[2].dtype == dtype:
+    if hit is not None and hit[0]() is w and hit[1] == _versions((w,)) and hit[2].dtype == dtype:
         return hit[2]
     if pad:
         w2 = _c(w2)
@@ -147,12 +196,13 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
                                                        wt.stride(0), R, C, _stream()), 'istvt_cast_transpose')
             tkey = (id(out), 'T')
             _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey, c=_wcache: c.pop(k, None)), 0, wt)
+            _operands[key] = ((weakref.ref(w),), out, wt)          # refreshed in place by refresh_stale_operands()
         else:
             _lib.check(_lib.lib().istvt_cast2d(w2.data_ptr(), dtype_code(w2), C, out.data_ptr(), _DT[dtype],
                                                out.stride(0), R, C, _stream()), 'istvt_cast2d')
     else:
         out = cast(w2, dtype)
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), (w._version, _wepoch[0]), out)
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), _versions((w,)), out)
     return out
 
 
@@ -164,7 +214,7 @@ def weight_cat_as(ws, dtype: torch.dtype) -> Tensor:
     weights."""
     ws = tuple(ws)
     key = (tuple(id(w) for w in ws), 'cat')
-    ver = tuple(w._version for w in ws) + (_wepoch[0],)
+    ver = _versions(ws)
     hit = _wcache.get(key)
     if hit is not None and all(r() is w for r, w in zip(hit[0], ws)) and hit[1] == ver and hit[2].dtype == dtype:
         return hit[2]
@@ -192,6 +242,7 @@ def weight_cat_as(ws, dtype: torch.dtype) -> Tensor:
     if wt is not None:
         tkey = (id(out), 'T')
         _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey, c=_wcache: c.pop(k, None)), 0, wt)
+        _operands[key] = (tuple(weakref.ref(w) for w in ws), out, wt)
     drop = lambda _r, k=key, c=_wcache: c.pop(k, None)
     _wcache[key] = (tuple(weakref.ref(w, drop) for w in ws), ver, out)
     return out

@@ -52,6 +52,27 @@ class BNState:
 _REPLICAS = None
 
 
+# Statistics accumulators are consumed (reduced, finalised) by the launches that directly follow their producer, so
+# they carry nothing from one training step to the next: instead of one torch.zeros() per accumulator (34 fill launches
+# per step at C2, each shorter than the ~5 us a launch occupies the queue for) they are cut from ONE arena that
+# stats_arena_reset() zeroes with a single fill at the start of a step.  Sized by the previous step's demand; anything
+# that does not fit (first step, other models on the same device) falls back to its own zeroed tensor.
+_arena = {'buf': None, 'off': 0, 'need': 0}
+
+
+def stats_arena_reset(device):
+    a = _arena
+    a['need'] = max(a['need'], a['off'])
+    a['off'] = 0
+    if a['need'] == 0:
+        return
+    buf = a['buf']
+    if buf is None or buf.device != torch.device(device) or buf.numel() < a['need']:
+        a['buf'] = torch.zeros((a['need'],), dtype=torch.float64, device=device)
+    else:
+        buf.zero_()
+
+
 def new_stats(C: int, device) -> Tensor:
     """zeroed per-channel statistics accumulator double[R][2][C]; kernels add into replica
     (workgroup % R) to spread same-address atomics, reduce_stats() folds them into replica 0."""
@@ -59,6 +80,13 @@ def new_stats(C: int, device) -> Tensor:
     if _REPLICAS is None:
         fn = _lib.lib().istvt_stats_replicas
         _REPLICAS = int(fn())
+    a = _arena
+    n = _REPLICAS * 2 * C
+    off = a['off']
+    a['off'] = off + n
+    buf = a['buf']
+    if buf is not None and buf.device == torch.device(device) and off + n <= buf.numel():
+        return buf[off:off + n].view(_REPLICAS, 2, C)
     return torch.zeros((_REPLICAS, 2, C), dtype=torch.float64, device=device)
 
 
@@ -166,6 +194,20 @@ def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn
                                              dw.data_ptr(), ws.data_ptr(), ws.numel(), Fr, H, W, C, dtype_code(x), _stream()),
                    'istvt_dwconv3x3_wgrad')
     return dw
+
+
+def tap_major(w: Tensor) -> Tensor:
+    """depthwise weight (C, 1, 3, 3) -> float32 [9][C] (the layout istvt_dwconv3x3 takes), cached until the parameter
+    changes (one small strided copy per weight per step otherwise)"""
+    key = (id(w), 'tap')
+    hit = ops._wcache.get(key)
+    ver = ops._versions((w,))
+    if hit is not None and hit[0]() is w and hit[1] == ver:
+        return hit[2]
+    out = w.detach().reshape(w.shape[0], 9).t().contiguous()
+    import weakref
+    ops._wcache[key] = (weakref.ref(w, lambda _r, k=key, c=ops._wcache: c.pop(k, None)), ver, out)
+    return out
 
 
 def _conv1_weight(w: Tensor, dtype) -> Tensor:
@@ -277,11 +319,11 @@ class StemFn(Function):
             M = Fr * H * H
             Hs = (H - 1) // 2 + 1
             Ms = Fr * Hs * Hs
-            wdwA = P['%s.rep.%d.conv1.weight' % (name, i0)].detach().reshape(cin_, 9).t().contiguous()   # tap-major [9][C]
-            wpwA = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0)], dtype)
-            wdwB = P['%s.rep.%d.conv1.weight' % (name, i0 + 3)].detach().reshape(cout, 9).t().contiguous()
-            wpwB = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0 + 3)], dtype)
-            wsk = ops.weight_as(P[name + '.skip.weight'], dtype)
+            wdwA = tap_major(P['%s.rep.%d.conv1.weight' % (name, i0)])               # tap-major [9][C], cached per version
+            wpwA = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0)], dtype, pad=True)
+            wdwB = tap_major(P['%s.rep.%d.conv1.weight' % (name, i0 + 3)])
+            wpwB = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0 + 3)], dtype, pad=True)
+            wsk = ops.weight_as(P[name + '.skip.weight'], dtype, pad=True)
             d1 = dwconv(X, wdwA, Fr, H, H, cin_, in_relu=pre_relu)
             uA, bnA = pw_bn('%s.rep.%d' % (name, i0 + 1), d1, wpwA, M, cout)
             d2 = dwconv(uA, wdwB, Fr, H, H, cout, in_bn=bnA, in_relu=True)
@@ -456,8 +498,10 @@ def stem_forward(x: Tensor, xcep: torch.nn.Module, dtype: torch.dtype) -> Tensor
     buffers = []
     for n in bn_names():
         buffers += [xcep.get_buffer(n + '.running_mean'), xcep.get_buffer(n + '.running_var')]
+    if x.is_cuda:
+        stats_arena_reset(x.device)          # one fill for every statistics accumulator of this step
+        ops.refresh_stale_operands()         # one grouped cast for every bf16 weight operand the optimizer invalidated
     y = StemFn.apply(x, dtype, xcep.training, buffers, *params)
     if xcep.training:
-        for n in bn_names():
-            xcep.get_buffer(n + '.num_batches_tracked').add_(1)
+        torch._foreach_add_([xcep.get_buffer(n + '.num_batches_tracked') for n in bn_names()], 1)     # one launch, not 11
     return y

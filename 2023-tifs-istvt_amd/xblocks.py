@@ -22,6 +22,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _lib, ops
+from . import stem as _stem
 from .ops import _c, _req, _stream, dtype_code
 from .stem import bn_apply, bn_backward, bn_forward_stats, dwconv, dwconv_wgrad, new_stats, pointwise_bn
 
@@ -41,8 +42,8 @@ def nchw_view(y: Tensor) -> Tensor:
 
 
 def _tap_major(w: Tensor) -> Tensor:
-    """depthwise weight (C, 1, 3, 3) -> float32 [9][C] (the layout istvt_dwconv3x3 takes)"""
-    return w.detach().reshape(w.shape[0], 9).t().contiguous()
+    """depthwise weight (C, 1, 3, 3) -> float32 [9][C] (the layout istvt_dwconv3x3 takes), cached per parameter version"""
+    return _stem.tap_major(w)
 
 
 def _fused_target(q: Tensor, shape):
@@ -61,7 +62,7 @@ class SepConvFn(Function):
         _req(x, 'SeparableConv2d input')
         cin, cout = wdw.shape[0], wpw.shape[0]
         w9 = _tap_major(wdw)
-        wp = ops.weight_as(wpw, x.dtype)
+        wp = ops.weight_as(wpw, x.dtype, pad=True)
         d = dwconv(x, w9, Fr, H, W, cin)
         u = ops.linear_fwd(d, wp, blocked=False)
         ctx.save_for_backward(x, d, wdw, wpw)
@@ -74,7 +75,7 @@ class SepConvFn(Function):
         x, d, wdw, wpw = ctx.saved_tensors
         Fr, H, W, cin, cout = ctx.geom
         du = _c(du)
-        wp = ops.weight_as(wpw, du.dtype)
+        wp = ops.weight_as(wpw, du.dtype, pad=True)
         dd = ops.linear_dgrad(du, wp, blocked=False)
         t = _fused_target(wpw, (cout, cin))
         gpw = ops.linear_wgrad(du, d, out=t)
@@ -126,7 +127,7 @@ class RepChainFn(Function):
             rm, rv = buffers[2 * i], buffers[2 * i + 1]
             relu = spec.start_with_relu if i == 0 else True
             w9 = _tap_major(wdw)
-            wp = ops.weight_as(wpw, dtype)
+            wp = ops.weight_as(wpw, dtype, pad=True)
             d = dwconv(X, w9, Fr, H, W, cin, in_bn=in_bn, in_relu=relu)
             u, bn = pointwise_bn(d, wp, M, cout, g, b, rm, rv, training)
             units.append(dict(X=X, in_bn=in_bn, relu=relu, d=d, u=u, bn=bn, w9=w9, wp=wp, cin=cin, cout=cout))
@@ -136,7 +137,7 @@ class RepChainFn(Function):
         if spec.has_skip:
             wsk, gs, bs = params[4 * nu: 4 * nu + 3]
             rms, rvs = buffers[2 * nu], buffers[2 * nu + 1]
-            ws = ops.weight_as(wsk, dtype)
+            ws = ops.weight_as(wsk, dtype, pad=True)
             if spec.tail == 'pool':
                 Hs, Ws = (H - 1) // 2 + 1, (W - 1) // 2 + 1
                 xs = torch.empty((Fr * Hs * Ws, spec.cin), dtype=dtype, device=dev)

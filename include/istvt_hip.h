@@ -275,6 +275,10 @@ int istvt_cast2d(const void* in, int in_dtype, long ldi, void* out, int out_dtyp
  * operand copies of a Linear weight for the forward and the input-gradient GEMMs (R, C multiples of 8) */
 int istvt_cast_transpose(const float* in, long ldi, void* out, long ldo, void* outT, long ldt, int R, int C,
                          istvt_stream_t stream);
+/* the same for `count` weights in one launch (groups of 32): the bf16 operand copies of every nn.Linear weight the
+ * optimizer has just changed, refreshed at the start of a step instead of one launch per weight */
+int istvt_cast_transpose_group(int count, const float* const* in, const long* ldi, void* const* out, const long* ldo,
+                               void* const* outT, const long* ldt, const int* R, const int* C, istvt_stream_t stream);
 
 /* ---- fused optimizer steps over flat float buffers (train_CNN.py:196-201: torch.optim.SGD(momentum) / AdamW) ----
  * p, g, state: n floats each, 16-byte aligned (parallel.GradBucket(flatten_params=True)).  Semantics are torch.optim's:
