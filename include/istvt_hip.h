@@ -265,7 +265,10 @@ int istvt_colsum(const void* x, float* out, long M, int N, long ld, float* ws, l
 int istvt_colsum_ws_elems(long M, int N);
 /* out[i] += sum_{r < rows} ws[r * n + i], rows added in index order by one writer per element: the second stage of every
  * per-column sum of this library (fp32 split-K slabs of narrow weight gradients, bias / token / BatchNorm-affine
- * gradients) -- no floating-point atomics anywhere, so a training step is bit-reproducible */
+ * gradients).  No kernel adds float32 values with atomics; the only atomics left are the double-precision statistics
+ * accumulators (BatchNorm sums, the GELU-backward column sums), whose addends are float32 partial sums: a 53-bit
+ * accumulator adds 24-bit addends exactly over any realistic spread of magnitudes, so their order does not change
+ * the result.  A training step gives the same bits on every run (tests/test_model_gpu.py). */
 int istvt_rows_reduce(const float* ws, int rows, long n, float* out, istvt_stream_t stream);
 int istvt_cast(const void* in, int in_dtype, void* out, int out_dtype, long n, istvt_stream_t stream);
 /* rows x cols cast between row-strided buffers (bf16 operand copies of fp32 weights with line-aligned rows) */

@@ -815,3 +815,25 @@ def test_training_step_is_bit_reproducible(dtype):
                     bad.append((n, float((fl[off:off + k] - runs[0][1][off:off + k]).abs().max())))
                 off += k
             raise AssertionError('gradients differ between two runs of the same step: %s' % bad[:12])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_self_launch_rehearsal():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE: the parent starts the two ranks
+    itself (child processes, never an exec; it does not touch the GPU) and relays rank 0's one JSON line.  Rehearsal mode:
+    both ranks on this one GPU over gloo -- functional only; RCCL needs the multi-GPU node the driver has."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['ISTVT_BENCH_REHEARSAL'] = '1'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+           '--frames', '4', '--size', '96', '--depth', '2', '--no-cpu-baseline', '--host-boundary']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['distributed']['ranks'] == 2 and out['distributed']['backend'] == 'gloo'
+    assert out['value'] > 0 and out['scaling'] == 'weak'
+    assert out['with_host_boundary']['ms_per_step'] > 0
