@@ -529,8 +529,10 @@ struct DwArgs {
 
 // load the (TH+2)x(TW+2)xCC input tile (zero outside the image; the on-load transform only
 // touches in-image pixels, i.e. the conv's zero padding is applied AFTER BN/ReLU as in the reference)
-template <typename T>
-__device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
+// TT = element type of the LDS tile: T for the forward / input-gradient kernels, float for the weight-gradient kernel
+// (see there).
+template <typename T, typename TT = T>
+__device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
                                              int W, int C, const float* bnp, int relu, int tid) {
     constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
     constexpr int NIT = (NVEC + 255) / 256;
@@ -577,6 +579,17 @@ __device__ __forceinline__ void dw_load_tile(T* tile, const T* __restrict__ in, 
     }
 }
 
+// Items of a thread in dwconv3x3_kernel: FOUR VERTICALLY ADJACENT pixels of one column (a 4 x 1 strip) and one 8-channel
+// chunk.  The strip's 12 (item, vertical tap) pairs touch only 6 distinct input rows, so per horizontal tap a thread
+// reads (and converts to float) 6 chunks instead of 12: half the LDS reads and half the bf16 -> float conversions of a
+// kernel that is issue-bound (8 of the ~13 vector instructions per (item, tap) were conversions).
+static_assert(DW_TH == 8 && DW_TW == 16 && DW_ITEMS == 4, "strip mapping: 2 strips of 4 rows x 16 columns");
+__device__ __forceinline__ void dw_strip(int tid, int& strip, int& px) {
+    const int pix0 = tid / DW_NCH;              // 0 .. 31
+    strip = pix0 / DW_TW;
+    px = pix0 % DW_TW;
+}
+
 // EPI = false: plain convolution (the forward launches).  The mask / skip-add / statistics epilogue of the input-
 // gradient launches costs ~90 registers; compiled into one kernel it left the forward at two workgroups per CU too.
 template <typename T, bool EPI>
@@ -608,10 +621,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     const int ashift = addfull ? 0 : 1;
     if constexpr (EPI) {
         const int cq = c0 + (tid % DW_NCH) * 8;
+        int strip_, px_;
+        dw_strip(tid, strip_, px_);
 #pragma unroll
         for (int k = 0; k < DW_ITEMS; ++k) {
-            const int pix = tid / DW_NCH + DW_PIXSTEP * k;
-            const int y = y0 + pix / DW_TW, x = x0 + pix % DW_TW;
+            const int y = y0 + strip_ * DW_ITEMS + k, x = x0 + px_;
             mraw[k] = Mma<T>::zero(); araw[k] = Mma<T>::zero();
             if (y < p.H && x < p.W && cq < p.C) {
                 if (p.msrc) mraw[k] = frag_load((const T*)p.msrc + ((f * p.H + y) * p.W + x) * p.C + cq);
@@ -661,31 +675,52 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) accs[k][j] = 0.f;
     {
-        const int pix0 = tid / DW_NCH;
-        const int py0 = pix0 / DW_TW, px0 = pix0 % DW_TW;
-        constexpr int ROWSTEP = DW_PIXSTEP / DW_TW;         // tile rows between a thread's consecutive items
-        static_assert(DW_PIXSTEP % DW_TW == 0, "a thread's items share their column");
-        const T* tbase = tile + (py0 * DW_LW + px0) * DW_CC + ch * 8;
+        int strip, px0;
+        dw_strip(tid, strip, px0);
+        const T* tbase = tile + ((strip * DW_ITEMS) * DW_LW + px0) * DW_CC + ch * 8;
         const float* wbase = &wsm[0][ch * 8];
+        if constexpr (sizeof(T) == 4) {
+            // float32 parity mode keeps the tap-major order of every item's nine products (dy outer, dx inner): it is the
+            // order of the reference's CPU convolution, and with the goldens' structured weights another order flips ReLU /
+            // arg-max decisions at |z| ~ 1e-7 (stem_oracle_139_f32 holds 2e-4 only in this order)
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {                 // a real loop: nothing of tap t + 1 is live during tap t
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            float w8[8];
-            load8(wbase + tap * DW_CC, w8);
-            const T* tp = tbase + (dy * DW_LW + dx) * DW_CC;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                float w8[8];
+                load8(wbase + tap * DW_CC, w8);
 #pragma unroll
-            for (int k = 0; k < DW_ITEMS; ++k) {
-                float v[8];
-                load8(tp + ROWSTEP * k * DW_LW * DW_CC, v);
+                for (int k = 0; k < DW_ITEMS; ++k) {
+                    float v[8];
+                    load8(tbase + ((k + dy) * DW_LW + dx) * DW_CC, v);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) accs[k][j] += v[j] * w8[j];
+                    for (int j = 0; j < 8; ++j) accs[k][j] += v[j] * w8[j];
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int dx = 0; dx < 3; ++dx) {                // a real loop: nothing of column tap dx + 1 is live during dx
+                float w8[3][8];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) load8(wbase + (dy * 3 + dx) * DW_CC, w8[dy]);
+#pragma unroll
+                for (int r = 0; r < DW_ITEMS + 2; ++r) {    // input row r of the strip feeds item k through tap dy = r - k
+                    float v[8];
+                    load8(tbase + (r * DW_LW + dx) * DW_CC, v);
+#pragma unroll
+                    for (int k = 0; k < DW_ITEMS; ++k) {
+                        const int dy = r - k;
+                        if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) accs[k][j] += v[j] * w8[dy][j];
+                    }
+                }
             }
         }
     }
     auto item = [&](const int k) {
-        const int pix = tid / DW_NCH + DW_PIXSTEP * k;
-        const int py = pix / DW_TW, px = pix % DW_TW;
-        const int y = y0 + py, x = x0 + px;
+        int strip, px;
+        dw_strip(tid, strip, px);
+        const int y = y0 + strip * DW_ITEMS + k, x = x0 + px;
         if (y >= p.H || x >= p.W || c >= p.C) return;
         float acc[8];
 #pragma unroll
@@ -796,7 +831,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
                                                               int in_relu,
                                                               const T* __restrict__ dout, float* __restrict__ dw,
                                                               int Fr, int H, int W, int C) {
-    __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
+    // The LDS tile of THIS kernel holds floats whatever the storage dtype: every input element is used by nine taps, and
+    // with a bf16 tile each use converted it again -- in a kernel that is issue-bound at two wavefronts per SIMD
+    // (SQ_ACTIVE_INST_ANY 0.47 of the wave cycles).  Measured at C2 (tools/stem_bench.py, same box): 280 -> 251, 476 ->
+    // 429, 278 -> 253, 233 -> 218 us for the four shapes.  The forward / input-gradient kernels keep a bf16 tile: a float
+    // tile takes them from 5 / 4 to 3 workgroups per CU and they lose 10-25 %.
+    __shared__ __attribute__((aligned(16))) float tile[DW_TILE_ELEMS];
     __shared__ float sred[4][DW_NCH][72];
     const int tid = threadIdx.x;
     const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
@@ -824,7 +864,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
             const int y = y0 + pix / DW_TW, x = x0 + pix % DW_TW;
             if (y < H && x < W && c < C) draw[k] = frag_load(dout + ((f * H + y) * W + x) * C + c);
         }
-        dw_load_tile<T>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
+        dw_load_tile<T, float>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < DW_ITEMS; ++k) {

@@ -431,7 +431,7 @@ def main():
             # the committed counters describe THIS code only if every GEMM kernel that just ran is in them with the same
             # launches per step; otherwise the file is stale (another kernel mix) and no traffic figure is printed
             stale = [k for k, v in by.items() if k.startswith('gemm256')
-                     and (rec_of(k) is None or rec_of(k).get('FETCH_SIZE', {}).get('launches_per_step', v[2]) != v[2])]
+                     and (rec_of(k) is None or rec_of(k).get('FETCH_SIZE', {}).get('launches_per_step') != v[2])]
             rec = rec_of(dom)
             if not stale and rec and 'FETCH_SIZE' in rec and 'WRITE_SIZE' in rec:
                 roof['traffic'] = round((2.0 * rec['FETCH_SIZE']['avg_KB'] + rec['WRITE_SIZE']['avg_KB']) * 1024)
