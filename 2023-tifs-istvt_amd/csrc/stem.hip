@@ -530,8 +530,11 @@ struct DwArgs {
 // load the (TH+2)x(TW+2)xCC input tile (zero outside the image; the on-load transform only
 // touches in-image pixels, i.e. the conv's zero padding is applied AFTER BN/ReLU as in the reference)
 // TT = element type of the LDS tile: T for the forward / input-gradient kernels, float for the weight-gradient kernel
-// (see there).
-template <typename T, typename TT = T>
+// (see there).  SWZ (float tiles only): the two 16-byte halves of a pixel's 8-channel chunk are swapped in odd LDS pixels.
+// A float pixel is 256 bytes = all 64 banks, and a 16-byte access of 16 lanes covers TWO adjacent pixels x 8 chunks x
+// one half: without the swap both pixels hit the same 32 banks (a 2-way conflict on every store and every tap read:
+// SQ_LDS_BANK_CONFLICT was 48 % of the LDS cycles of the weight-gradient kernel), with it they split the banks.
+template <typename T, typename TT = T, bool SWZ = false>
 __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
                                              int W, int C, const float* bnp, int relu, int tid) {
     constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
@@ -575,7 +578,15 @@ __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in,
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             }
         }
-        store8(tile + (py * DW_LW + px) * DW_CC + ch * 8, v);
+        if constexpr (SWZ) {
+            static_assert(sizeof(TT) == 4 && DW_LW % 2 == 0, "swizzled tile: float, even row pitch");
+            float* dst = reinterpret_cast<float*>(tile) + (py * DW_LW + px) * DW_CC + ch * 8;
+            const int o = (px & 1) * 4;
+            *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4 - o) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            store8(tile + (py * DW_LW + px) * DW_CC + ch * 8, v);
+        }
     }
 }
 
@@ -845,6 +856,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     const int bid = xcd_chunk(blockIdx.x, gridDim.x);
     const int c0 = (int)(bid % nch) * DW_CC;
     const int ch = tid % DW_NCH, c = c0 + ch * 8;
+    const int o0 = ((tid / DW_NCH) & 1) * 4;         // parity of this thread's pixel column (DW_PIXSTEP and DW_TW are even)
     float acc[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -864,7 +876,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
             const int y = y0 + pix / DW_TW, x = x0 + pix % DW_TW;
             if (y < H && x < W && c < C) draw[k] = frag_load(dout + ((f * H + y) * W + x) * C + c);
         }
-        dw_load_tile<T, float>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
+        dw_load_tile<T, float, true>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < DW_ITEMS; ++k) {
@@ -884,8 +896,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    float v[8];
-                    load8(tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8, v);
+                    // swizzled tile (dw_load_tile<.., SWZ>): halves swapped in odd LDS pixels; px + dx has the parity of
+                    // the thread's pixel for dx = 0, 2 and the other one for dx = 1
+                    const float* tp = tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8;
+                    const int o = (dx & 1) ? 4 - o0 : o0;
+                    const float4 lo = *reinterpret_cast<const float4*>(tp + o);
+                    const float4 hi = *reinterpret_cast<const float4*>(tp + 4 - o);
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[dy * 3 + dx][j] += d[j] * v[j];
                 }

@@ -12,6 +12,7 @@ parameters (block4..fc) that ``low_level_features`` never touches.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Iterable, List, Tuple
 
@@ -19,6 +20,13 @@ import torch
 import torch.distributed as dist
 
 from . import stem as _stem
+
+
+def _single_rank(group=None) -> bool:
+    """True when the collectives can be skipped: a world of one rank.  ISTVT_FORCE_COLLECTIVES=1 runs them anyway -- on a
+    one-GPU box that is the only way to drive RCCL through exactly the calls, streams and waits of the N > 1 path
+    (`bench.py --rccl-rehearsal`); a one-rank all-reduce leaves the values unchanged."""
+    return dist.get_world_size(group) == 1 and os.environ.get('ISTVT_FORCE_COLLECTIVES') != '1'
 
 
 def live_named_parameters(model: torch.nn.Module) -> List[Tuple[str, torch.nn.Parameter]]:
@@ -105,7 +113,7 @@ class GradBucket:
                 return
             if not (dist.is_available() and dist.is_initialized()):
                 return
-            if dist.get_world_size(group) == 1 or device != me.flat.device:
+            if _single_rank(group) or device != me.flat.device:
                 return
             if me._early_work is not None:
                 # a second backward before all_reduce() (gradient accumulation): its kernels would add into the slice
@@ -155,7 +163,7 @@ class GradBucket:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if _single_rank(group):
             return
         if self._early_work is not None:    # the transformer's slice is already in flight (enable_early_all_reduce)
             work, lo = self._early_work     # (lo travels with the work: disable_early_all_reduce() may have run since)
@@ -177,7 +185,7 @@ class GradBucket:
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
     """identical weights/buffers on every rank (DataParallel replicates module 0 each step)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or _single_rank(group):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src, group=group)

@@ -72,6 +72,13 @@ def parse():
                     help='extra field with_host_boundary: the same K steps with the reference loop\'s host side in the timed '
                          'region (train_CNN.py:506,512,534-536): per-step H2D copy of the (B,T,3,S,S) batch from pinned memory '
                          '(double-buffered on a copy stream), loss.item() and the accuracy count; NOT the headline value')
+    ap.add_argument('--rccl-rehearsal', action='store_true',
+                    help='N = 1 only: initialise an RCCL ("nccl") process group of ONE rank and run every collective of the '
+                         'N > 1 path anyway (ISTVT_FORCE_COLLECTIVES=1: parameter broadcast, the early asynchronous '
+                         'all-reduce of the transformer slice from inside backward, the blocking rest, barriers, the per-rank '
+                         'time gather).  On a one-GPU box this is the only way to drive RCCL itself through the calls, streams '
+                         'and waits of the data-parallel step; values are unchanged and the timing says what the calls cost '
+                         'without any link')
     ap.add_argument('--plumbing-only', action='store_true',
                     help='exercise only the launch / process-group / timing / JSON plumbing (no model, no GPU needed): '
                          'what the CPU test of the self-launching --gpus N path runs')
@@ -212,6 +219,16 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
+        if a.rccl_rehearsal:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+                s.bind(('127.0.0.1', 0))
+                port = s.getsockname()[1]
+            os.environ['ISTVT_FORCE_COLLECTIVES'] = '1'
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    # `multi`: the collectives of the data-parallel step run (N > 1, or the one-rank RCCL rehearsal)
+    multi = world > 1 or a.rccl_rehearsal
     dev = torch.device('cuda', local_rank)
 
     import istvt_pkg
@@ -235,7 +252,7 @@ def main():
     else:                                   # the same update in one launch over the flat buffers, zero-grad included
         opt = parallel.FusedSGD(bucket, lr=1e-3, momentum=0.9, weight_decay=0, zero_grad=True)
     crit = torch.nn.BCEWithLogitsLoss()                                      # train_CNN.py:148
-    if world > 1 and not a.no_early_allreduce:
+    if multi and not a.no_early_allreduce:
         # the transformer's 98.8 % of the bucket is all-reduced while the stem backward still runs (parallel.py)
         bucket.enable_early_all_reduce(next(i for i, (n, _) in enumerate(live_named) if n.startswith('vit.')))
 
@@ -270,7 +287,7 @@ def main():
         return (loss, logits) if want_logits else loss
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -288,7 +305,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     per_rank = None
-    if world > 1:
+    if multi:
         # every rank's own time for the K steps (the first N > 1 run on real hardware should diagnose itself: a slow rank,
         # a slow link or the collective show up here), then the MAX over ranks as the job's time
         mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -309,7 +326,7 @@ def main():
             step()
         sync()
         e2 = time.perf_counter() - t1
-        if world > 1:
+        if multi:
             t = torch.tensor([e2], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e2 = float(t.item())
@@ -353,7 +370,7 @@ def main():
         hb_steps(a.steps)
         sync()
         e3 = time.perf_counter() - t1
-        if world > 1:
+        if multi:
             t = torch.tensor([e3], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e3 = float(t.item())
@@ -456,7 +473,7 @@ def main():
                                    '(fwd+bwd+grad all-reduce+SGD), random-init weights'
                                    % (config_name(a, world), a.batch, a.frames, a.size, a.size, a.depth),
                        'global_batch': world * a.batch, 'frames': a.frames, 'size': a.size, 'depth': a.depth,
-                       'parallelism': 'dp%d' % world, 'early_allreduce': bool(world > 1 and not a.no_early_allreduce), 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
+                       'parallelism': 'dp%d' % world, 'early_allreduce': bool(multi and not a.no_early_allreduce), 'loss': round(loss_val, 5), 'attn_fp8': bool(a.attn_fp8)},
         }
         gf = GF_PER_CLIP_FWD_BWD.get(a.frames) if (a.size == 224 and a.depth == 12) else None
         if gf and a.eval:
@@ -475,11 +492,12 @@ def main():
             out['with_dead_row_elimination'] = dre
         if hostb:
             out['with_host_boundary'] = hostb
-        if world > 1:
+        if multi:
             out['distributed'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                   'per_rank_ms_per_step': per_rank,
                                   'grad_bucket_MB': round(bucket.numel * 4 / 2**20, 1),
-                                  'scale_folded_into_optimizer': bool(bucket.defer_scale)}
+                                  'scale_folded_into_optimizer': bool(bucket.defer_scale),
+                                  'rccl_rehearsal': bool(a.rccl_rehearsal)}
         ms = torch.cuda.memory_stats(dev)
         out['allocator'] = {'reserved_GB': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),
                             'device_allocs': ms.get('num_device_alloc', 0), 'device_frees': ms.get('num_device_free', 0),
@@ -491,7 +509,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not a.eval:
             out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -837,3 +837,31 @@ def test_bench_gpus_n_self_launch_rehearsal():
     assert out['n_gpus'] == 2 and out['distributed']['ranks'] == 2 and out['distributed']['backend'] == 'gloo'
     assert out['value'] > 0 and out['scaling'] == 'weak'
     assert out['with_host_boundary']['ms_per_step'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_one_rank_rehearsal():
+    """RCCL itself (backend "nccl"), driven through every collective of the data-parallel step on this one GPU: a process
+    group of ONE rank with ISTVT_FORCE_COLLECTIVES=1 (`bench.py --rccl-rehearsal`) -- parameter broadcast, the asynchronous
+    all-reduce of the transformer slice started from inside backward next to the side-stream weight gradients, the blocking
+    all-reduce of the stem slice, work.wait(), barriers, the float64 all_gather of the per-rank times.  A one-rank sum
+    leaves the values unchanged, so the loss after the same steps must equal the plain run's to the last bit."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'ISTVT_BENCH_REHEARSAL')}
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--batch', '2', '--frames', '4',
+            '--size', '96', '--depth', '2', '--no-cpu-baseline', '--no-kernel-profile', '--no-dre-extra']
+    outs = []
+    for extra in ([], ['--rccl-rehearsal']):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, r.stdout[-2000:]
+        outs.append(json.loads(lines[0]))
+    plain, rccl = outs
+    assert 'distributed' not in plain
+    d = rccl['distributed']
+    assert d['backend'] == 'nccl' and d['ranks'] == 1 and d['rccl_rehearsal'] and len(d['per_rank_ms_per_step']) == 1
+    assert rccl['config']['early_allreduce'] and rccl['n_gpus'] == 1
+    assert rccl['config']['loss'] == plain['config']['loss']
