@@ -216,7 +216,8 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', rank=rank, world_size=world)
+            # device_id: the communicator is created now, on this rank's GPU, and barrier() knows its device
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     else:
         torch.cuda.set_device(0)
         if a.rccl_rehearsal:
@@ -226,7 +227,8 @@ def main():
                 port = s.getsockname()[1]
             os.environ['ISTVT_FORCE_COLLECTIVES'] = '1'
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                    device_id=torch.device('cuda', 0))
     # `multi`: the collectives of the data-parallel step run (N > 1, or the one-rank RCCL rehearsal)
     multi = world > 1 or a.rccl_rehearsal
     dev = torch.device('cuda', local_rank)

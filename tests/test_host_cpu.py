@@ -175,6 +175,49 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     assert res['err'] < 1e-6
 
 
+def test_force_collectives_in_a_world_of_one(tmp_path, pkg):
+    """ISTVT_FORCE_COLLECTIVES=1 (what `bench.py --rccl-rehearsal` sets): a one-rank process group still goes through every
+    collective of the data-parallel step -- early asynchronous slice, blocking rest, deferred 1/W -- and leaves the values
+    as they were.  Run in a child process: the process group is global state."""
+    script = tmp_path / 'force_worker.py'
+    script.write_text("""
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+os.environ['ISTVT_FORCE_COLLECTIVES'] = '1'
+import torch, torch.distributed as dist
+import istvt_pkg; istvt_pkg.load()
+from istvt_amd import parallel
+dist.init_process_group('gloo', init_method='file://' + sys.argv[1], rank=0, world_size=1)
+calls = []
+real = dist.all_reduce
+def counting(t, *a, **k):
+    calls.append(t.numel())
+    return real(t, *a, **k)
+dist.all_reduce = counting
+lin = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 1))
+parallel.broadcast_parameters(lin)
+params = list(lin.parameters())
+bucket = parallel.GradBucket(params)
+for p in params:
+    p._istvt_fused_grad = True
+bucket.zero()
+lin(torch.ones(3, 6)).sum().backward()
+before = bucket.flat.clone()
+bucket.enable_early_all_reduce(2)
+bucket._on_ready(bucket.flat.device)
+early = bucket._early_work is not None
+bucket.all_reduce()
+print(json.dumps({'single': parallel._single_rank(), 'early': early, 'calls': calls,
+                  'same': bool(torch.equal(before, bucket.flat)), 'numel': bucket.numel}))
+dist.destroy_process_group()
+""" % {'root': ROOT})
+    r = subprocess.run([sys.executable, str(script), str(tmp_path / 'store')], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['single'] is False and res['early'] and res['same']
+    assert res['calls'] == [6, 35] and res['numel'] == 41        # early: the last Linear's slice; then the first one's
+
+
 def test_bench_cli_contract():
     src = open(os.path.join(ROOT, 'bench.py')).read()
     for flag in ('--gpus', '--steps', '--warmup'):
