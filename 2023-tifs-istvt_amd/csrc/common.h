@@ -245,3 +245,22 @@ __device__ __forceinline__ f32frag frag_load_tr(const float* img, int ld, int k0
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- LDS-DMA ---------------------------------------------------------------------------------
+// LDS-DMA as inline assembly: 16 bytes per lane from (descriptor, per-lane offset voff, scalar offset soff) to the LDS
+// byte address lds_addr + 16 * lane.  The builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) is a store to LDS as far as
+// the compiler knows, so every LDS read that FOLLOWS it in program order gets an s_waitcnt vmcnt(0) in front: a K loop can
+// then only issue its DMA after the fragment reads of the same slot.  This form is opaque: ordering against the LDS
+// reads is the kernel's own barrier / vmcnt protocol.  s_nop 4: one wait state between the write of M0 and the DMA,
+// five between a VALU write of an SGPR operand (v_readfirstlane) and the VMEM instruction that reads it.
+__device__ __forceinline__ void dma16_lds(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+
+// the same, 4 bytes per lane (lds_addr + 4 * lane)
+__device__ __forceinline__ void dma4_lds(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+

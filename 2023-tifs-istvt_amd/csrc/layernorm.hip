@@ -229,6 +229,164 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy1, 
     }
 }
 
+// The same backward for bf16 rows with the operands staged by LDS-DMA (round 3).  The register version above keeps ONE
+// row ahead per wavefront (its raw chunks cost 24 registers and the kernel already sits at two wavefronts per SIMD):
+// 35 KB in flight per CU, and SQ_WAIT_ANY 0.64 -- it waits on HBM latency, not on bandwidth.  Here every wavefront owns
+// a ring of LN_RING row slots in LDS; the rows LN_RING - 1 ahead are on their way while it reduces the current one,
+// with no register cost (buffer_load ... lds), and the wait is a counted vmcnt: all VMEM operations of the loop are
+// issued by hand in a fixed order (per row: the DMAs of dy, x [, dres], mean, rstd; then the dx stores), so
+// "row i has landed" is "all but the (LN_RING-1) * NLD + min(i, LN_RING) * NST youngest operations are done".
+// Rows past M and the lanes past D are sent out of range (no traffic, zeros in LDS), never branched around.
+constexpr int LN_RING = 3;
+constexpr int LN_SLOT_BYTES = 3 * 2048 + 512;          // dy, x, dres: 2 chunks of 1 KiB each; mean, rstd: 256 B each
+
+template <int N> __device__ __forceinline__ void ln_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool DCOL, bool HAS_RES, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restrict__ dy1, const bf16_t* __restrict__ x,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
+                                                         bf16_t* __restrict__ dx, float* __restrict__ ws, long M, int D,
+                                                         long ld_dy, long ld_x, long ld_res, long ld_dx) {
+    constexpr int NACC = DCOL ? 3 : 2;
+    constexpr int NARR = HAS_RES ? 3 : 2;
+    constexpr int NLD = NARR * NCH + 2, NST = NCH;     // VMEM operations per row: loads (DMA), stores
+    static_assert(NACC * 4 * LN_MAXCH * 512 * 4 <= 4 * LN_RING * LN_SLOT_BYTES, "the final reduction aliases the ring");
+    __shared__ __attribute__((aligned(16))) char smem[4 * LN_RING * LN_SLOT_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long wave = (long)blockIdx.x * 4 + wid;
+    const long nwaves = (long)gridDim.x * 4;
+    float gm[LN_MAXCH][8];
+    ln_row_load<float>(gamma, D, lane, gm);
+    float ag[LN_MAXCH][8], ab[LN_MAXCH][8], ac[DCOL ? LN_MAXCH : 1][8];
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; if (DCOL) ac[c][i] = 0.f; }
+    bool on[LN_MAXCH];
+    unsigned voff[LN_MAXCH];
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c) {
+        on[c] = c < NCH && (lane + 64 * c) * 8 < D;
+        voff[c] = on[c] ? (unsigned)((lane + 64 * c) * 16) : 0x80000000u;
+    }
+    auto uni = [](const void* q) -> char* {
+        const unsigned long long u = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (char*)(((unsigned long long)hi << 32) | lo);
+    };
+    constexpr unsigned FLAGS = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(uni(dy1), 0, (int)(M * ld_dy * 2), FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(uni(x), 0, (int)(M * ld_x * 2), FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_rs = __builtin_amdgcn_make_buffer_rsrc(uni(HAS_RES ? dres : x), 0, (int)(M * (HAS_RES ? ld_res : ld_x) * 2), FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_mu = __builtin_amdgcn_make_buffer_rsrc(uni(mean_in), 0, (int)(M * 4), FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_rd = __builtin_amdgcn_make_buffer_rsrc(uni(rstd_in), 0, (int)(M * 4), FLAGS);
+    typedef __attribute__((address_space(3))) void lds_v;
+    const unsigned ring0 = (unsigned)(__SIZE_TYPE__)(lds_v*)smem + wid * (LN_RING * LN_SLOT_BYTES);
+    const char* ringp = smem + wid * (LN_RING * LN_SLOT_BYTES);
+
+    // row i of this wavefront -> slot i % LN_RING; rows past M go out of range as a whole (scalar offset past num_records)
+    auto issue = [&](long i) {
+        const long m = wave + i * nwaves;
+        const bool ok = m < M;
+        const unsigned dst = ring0 + (unsigned)(i % LN_RING) * LN_SLOT_BYTES;
+        const int dead = ok ? 0 : 0x7fffffff;
+        const int s_dy = ok ? (int)(m * ld_dy * 2) : dead, s_x = ok ? (int)(m * ld_x * 2) : dead;
+        const int s_rs = ok ? (int)(m * ld_res * 2) : dead, s_m = ok ? (int)(m * 4) : dead;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            dma16_lds(rs_dy, dst + c * 1024, voff[c], s_dy);
+            dma16_lds(rs_x, dst + 2048 + c * 1024, voff[c], s_x);
+            if (HAS_RES) dma16_lds(rs_rs, dst + 4096 + c * 1024, voff[c], s_rs);
+        }
+        dma4_lds(rs_mu, dst + 6144, 0u, s_m);               // every lane gets its own copy of the row's mean / rstd
+        dma4_lds(rs_rd, dst + 6144 + 256, 0u, s_m);
+    };
+    const long n_rows = wave < M ? (M - wave + nwaves - 1) / nwaves : 0;
+#pragma unroll
+    for (int i = 0; i < LN_RING; ++i) issue(i);
+    for (long i = 0; i < n_rows; ++i) {
+        // row i landed: younger are the loads of rows i+1 .. i+LN_RING-1 and the stores of rows max(0, i-LN_RING) .. i-1
+        if (i >= LN_RING) ln_wait_vm<(LN_RING - 1) * NLD + LN_RING * NST>();
+        else if (i == 2) ln_wait_vm<(LN_RING - 1) * NLD + 2 * NST>();
+        else if (i == 1) ln_wait_vm<(LN_RING - 1) * NLD + 1 * NST>();
+        else ln_wait_vm<(LN_RING - 1) * NLD>();
+        static_assert(LN_RING == 3, "the three warm-up waits above");
+        const char* slot = ringp + (i % LN_RING) * LN_SLOT_BYTES;
+        bf16x8 rdy[LN_MAXCH], rx[LN_MAXCH], rr[LN_MAXCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            rdy[c] = *reinterpret_cast<const bf16x8*>(slot + c * 1024 + lane * 16);
+            rx[c] = *reinterpret_cast<const bf16x8*>(slot + 2048 + c * 1024 + lane * 16);
+            if (HAS_RES) rr[c] = *reinterpret_cast<const bf16x8*>(slot + 4096 + c * 1024 + lane * 16);
+        }
+        const float mean = *reinterpret_cast<const float*>(slot + 6144 + lane * 4);
+        const float rstd = *reinterpret_cast<const float*>(slot + 6144 + 256 + lane * 4);
+        // the slot is free once these reads have returned: refill it with row i + LN_RING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue(i + LN_RING);
+        const long m = wave + i * nwaves;
+        float dy[LN_MAXCH][8], xv[LN_MAXCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (on[c]) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    dy[c][k] = (float)rdy[c][k];
+                    const float xh = ((float)rx[c][k] - mean) * rstd;
+                    xv[c][k] = xh;
+                    const float gdy = dy[c][k] * gm[c][k];
+                    s1 += gdy;
+                    s2 += gdy * xh;
+                    ag[c][k] += dy[c][k] * xh;
+                    ab[c][k] += dy[c][k];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = on[c] ? rstd * (dy[c][k] * gm[c][k] - s1 - xv[c][k] * s2) : 0.f;
+            if (HAS_RES) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] += on[c] ? (float)rr[c][k] : 0.f;
+            }
+            if (DCOL) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ac[c][k] += o[k];
+            }
+            // exactly one store instruction per chunk (the count the waits above assume; chunk c < NCH always has active
+            // lanes).  A plain global store: the buffer form with the row in an SGPR offset hit the store-data hazard of
+            // gemm_shared.h (its data registers are overwritten by the next row's LDS reads a few instructions later).
+            if (on[c]) store8(dx + m * ld_dx + (lane + 64 * c) * 8, o);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the out-of-range refills of the last rows still target the ring
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [NACC][4][LN_MAXCH * 512]
+    constexpr int RW = LN_MAXCH * 512;
+#pragma unroll
+    for (int c = 0; c < LN_MAXCH; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[(0 * 4 + wid) * RW + (c * 64 + lane) * 8 + k] = ag[c][k];
+            red[(1 * 4 + wid) * RW + (c * 64 + lane) * 8 + k] = ab[c][k];
+            if (DCOL) red[((NACC - 1) * 4 + wid) * RW + (c * 64 + lane) * 8 + k] = ac[c][k];
+        }
+    __syncthreads();
+    float* mine = ws + (long)blockIdx.x * NACC * D;
+    for (int col = threadIdx.x; col < D; col += 256) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+            mine[a * D + col] = (red[(a * 4 + 0) * RW + col] + red[(a * 4 + 1) * RW + col]) + (red[(a * 4 + 2) * RW + col] + red[(a * 4 + 3) * RW + col]);
+    }
+}
+
 static int ln_grid(long rows) {
     static const long cap = istvt_tune("ISTVT_LN_BLOCKS", 4096);   // 2048 -> 4096: -8 % on the forward LayerNorm
     long blocks = (rows + 3) / 4;
@@ -270,7 +428,28 @@ extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, lo
     const long blocks = ln_bwd_blocks(M);
     const int nacc = dcol ? 3 : 2;
     if (ws_elems < blocks * nacc * D) return ISTVT_ERR_SHAPE;
-    if (dcol)
+    // bf16 rows whose operands fit 32-bit buffer offsets: the LDS-DMA ring kernel; everything else the register kernel
+    static const int dma_on = istvt_tune("ISTVT_LN_BWD_DMA", 1);
+    const long lim = 0x7fffffffL / 2;
+    const bool dma = dma_on && dtype == DT_BF16 && M * ld_dy < lim && M * ld_x < lim && M * ld_dx < lim && (!dres || M * ld_res < lim) &&
+                     ((uintptr_t)dy % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0 && (!dres || ((uintptr_t)dres % 16) == 0);
+    if (dma) {
+#define LN_DMA(DCOLV, RESV, NCHV)                                                                                          \
+    hipLaunchKernelGGL((ln_bwd_dma_kernel<DCOLV, RESV, NCHV>), dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)dy, \
+                       (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, ws, M, D, ld_dy, ld_x, ld_res, ld_dx)
+        const int sel = (dcol ? 4 : 0) | (dres ? 2 : 0) | (D > 512 ? 1 : 0);
+        switch (sel) {
+            case 0: LN_DMA(false, false, 1); break;
+            case 1: LN_DMA(false, false, 2); break;
+            case 2: LN_DMA(false, true, 1); break;
+            case 3: LN_DMA(false, true, 2); break;
+            case 4: LN_DMA(true, false, 1); break;
+            case 5: LN_DMA(true, false, 2); break;
+            case 6: LN_DMA(true, true, 1); break;
+            default: LN_DMA(true, true, 2); break;
+        }
+#undef LN_DMA
+    } else if (dcol)
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, true>), dim3((int)blocks), dim3(256), 0, stream,
                                                  (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, ws, M,
                                                  D, ld_dy, ld_x, ld_res, ld_dx));
