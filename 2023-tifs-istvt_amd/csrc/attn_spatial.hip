@@ -261,26 +261,34 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
         // online softmax in the log2 domain; lane owns query r of sub-tile u, keys 4g+j of each tile
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            // (TAIL: tiles wholly past P take no part -- their s stays 0 for the PV product --, and only the ONE tile that
+            //  straddles P is masked: both conditions are wave-uniform, so the row end costs branches, not a compare and
+            //  a select per score of the whole chunk)
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                if (TAIL && c0 + 16 * t >= P) continue;
+                if (TAIL && c0 + 16 * t + 16 > P) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (TAIL) s[t][u][j] = (c0 + 16 * t + 4 * g + j < P) ? s[t][u][j] : -INFINITY;
-                    mx = fmaxf(mx, s[t][u][j]);
+                    for (int j = 0; j < 4; ++j) s[t][u][j] = (c0 + 16 * t + 4 * g + j < P) ? s[t][u][j] : -INFINITY;
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[t][u][j]);
+            }
             mx = group_max(mx) * c;
             const float m_new = fmaxf(m_run[u], mx);
             const float alpha = fast_exp2(m_run[u] - m_new);
             float sum = 0.f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) {
+                if (TAIL && c0 + 16 * t >= P) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float pv = fast_exp2(fmaf(s[t][u][j], c, -m_new));
                     s[t][u][j] = pv;
                     sum += pv;
                 }
+            }
             sum = group_sum(sum);
             l_run[u] = l_run[u] * alpha + sum;
             m_run[u] = m_new;
@@ -476,6 +484,9 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
 #pragma unroll
                 for (int u = 0; u < U; ++u) { s[tt][u] = f32x4{0, 0, 0, 0}; dp[tt][u] = f32x4{0, 0, 0, 0}; }
                 const int krow = 32 * ss + 16 * tt + r;
+                // only the 16-key tile that holds the row end needs its scores masked (wave-uniform): a compare and a
+                // select per score of the whole tail chunk were 12 % of this kernel's instructions
+                const bool straddle = tail && c0 + 32 * ss + 16 * tt + 16 > P;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     typename Mma<T>::frag kf = frag_load(Kimg_c + krow * LDI + 32 * ks + 8 * g);
@@ -487,14 +498,18 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
                         Mma<T>::mma(dp[tt][u], vf, dof[u][ks]);
                     }
                 }
+                auto softmax_bwd = [&](auto masked) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                    for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float pv = fast_exp2(fmaf(s[tt][u][j], c, -lq[u]));
-                        if (tail && c0 + 32 * ss + 16 * tt + 4 * g + j >= P) pv = 0.f;
-                        s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]);               // dS^T / scale (applied to dQ below)
-                    }
+                        for (int j = 0; j < 4; ++j) {
+                            float pv = fast_exp2(fmaf(s[tt][u][j], c, -lq[u]));
+                            if (decltype(masked)::value && c0 + 32 * ss + 16 * tt + 4 * g + j >= P) pv = 0.f;
+                            s[tt][u][j] = pv * (dp[tt][u][j] - dl[u]);           // dS^T / scale (applied to dQ below)
+                        }
+                };
+                if (straddle) softmax_bwd(std::true_type{});
+                else softmax_bwd(std::false_type{});
             }
             typename Mma<T>::frag dsf[U];
 #pragma unroll
