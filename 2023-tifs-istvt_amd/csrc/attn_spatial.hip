@@ -377,11 +377,21 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
 
 // ------------------------------------------------------------------------------------------
 // backward part 1: delta = rowsum(dO o O), dQ
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
-__global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
-                                                           const T* __restrict__ dout, const float* __restrict__ lse,
-                                                           float* __restrict__ delta, T* __restrict__ dqkv, int P,
-                                                           int heads, float scale, long ldqkv, long ldo) {
+// The query / dO row fragments a wavefront loaded for its dQ blocks: together the wavefronts of a workgroup hold every
+// row of Q and dO, so the fused backward writes the Q / dO images of its second part from them instead of reading global
+// memory a second time.
+template <typename T, int DH, int U, int NBLK> struct SattnKeep {
+    typename Mma<T>::frag q[NBLK][U][DH / 32], d[NBLK][U][DH / 32];
+};
+
+// FUSED (sattn_bwd_fused_kernel): delta goes to the LDS row the dK / dV part reads it from instead of to global memory
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false, bool FUSED = false>
+__device__ __forceinline__ void sattn_dq_body(const T* __restrict__ qkv, const T* __restrict__ out,
+                                              const T* __restrict__ dout, const float* __restrict__ lse,
+                                              float* __restrict__ delta, T* __restrict__ dqkv, int P,
+                                              int heads, float scale, long ldqkv, long ldo,
+                                              SattnKeep<T, DH, U, RES ? RES_CHUNKS : 1>* keep = nullptr) {
+    static_assert(!FUSED || RES, "the fused backward is the keys-resident form");
     constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
     const int img_rows = RES ? res_img_rows(P) : CHUNK;
@@ -412,6 +422,7 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
                 qf_pre[qi][u][ks] = row_frag<T>(qp, ld, q, P, 32 * ks + 8 * g);
                 dof_pre[qi][u][ks] = row_frag<T>(dop, ldo, q, P, 32 * ks + 8 * g);
                 of_pre[qi][u][ks] = row_frag<T>(op, ldo, q, P, 32 * ks + 8 * g);
+                if constexpr (FUSED) { keep->q[qi][u][ks] = qf_pre[qi][u][ks]; keep->d[qi][u][ks] = dof_pre[qi][u][ks]; }
             }
             st_pre[qi][u] = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
         }
@@ -446,7 +457,13 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
         // exponent offset with 1/rowsum folded in: p = exp2(s c - (max - log2(1/sum))); rows past P have 1/sum = 0 ->
         // offset +inf -> p = 0
         lq[u] = st.x - __builtin_amdgcn_logf(st.y); li[u] = st.y;
-        if (q < P && g == 0) delta[((long)bf * P + q) * heads + h] = dl[u];
+        if constexpr (FUSED) {
+            // (rows P .. of an active wavefront are zero rows: dl = 0, as the dK / dV part wants them)
+            float* stat1 = reinterpret_cast<float*>(Kimg + 2 * img_rows * LDI) + img_rows;
+            if (g == 0 && q < img_rows) stat1[q] = dl[u];
+        } else {
+            if (q < P && g == 0) delta[((long)bf * P + q) * heads + h] = dl[u];
+        }
     }
 
     f32x4 dq[DT][U];
@@ -537,13 +554,22 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
   }   // query blocks
 }
 
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
+__global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                           const T* __restrict__ dout, const float* __restrict__ lse,
+                                                           float* __restrict__ delta, T* __restrict__ dqkv, int P,
+                                                           int heads, float scale, long ldqkv, long ldo) {
+    sattn_dq_body<T, DH, U, FP8, RES, false>(qkv, out, dout, lse, delta, dqkv, P, heads, scale, ldqkv, ldo);
+}
+
 // ------------------------------------------------------------------------------------------
 // backward part 2: dK, dV.  Wave owns 32 keys; queries stream through LDS.
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
-__global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
-                                                            const float* __restrict__ lse,
-                                                            const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                            int P, int heads, float scale, long ldqkv, long ldo) {
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false, bool FUSED = false>
+__device__ __forceinline__ void sattn_dkv_body(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                               const float* __restrict__ lse,
+                                               const float* __restrict__ delta, T* __restrict__ dqkv,
+                                               int P, int heads, float scale, long ldqkv, long ldo,
+                                               const SattnKeep<T, DH, U, RES ? RES_CHUNKS : 1>* keep = nullptr) {
     constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
     __shared__ __attribute__((aligned(16))) float stat_st[RES ? 4 : 2 * CHUNK];
@@ -572,15 +598,48 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int key = (RES ? ki : (int)blockIdx.x) * 128 + wave * 16 * U + 16 * kt + r;
-                kf_pre[ki][kt][ks] = row_frag<T>(kp, ld, key, P, 32 * ks + 8 * g);
-                vf_pre[ki][kt][ks] = row_frag<T>(vp, ld, key, P, 32 * ks + 8 * g);
+                if constexpr (FUSED) {
+                    // the dQ part left the K / V images of this (frame, head) in the bytes Q / dO are about to take:
+                    // the wavefront's own key rows come from there, not from global memory again
+                    const int kr = min(key, img_rows - 1);
+                    typename Mma<T>::frag kk = frag_load(Qimg + kr * LDI + 32 * ks + 8 * g);
+                    typename Mma<T>::frag vv = frag_load(Dimg + kr * LDI + 32 * ks + 8 * g);
+                    if (key >= P) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { Mma<T>::set(kk, i, 0.f); Mma<T>::set(vv, i, 0.f); }
+                    }
+                    kf_pre[ki][kt][ks] = kk;
+                    vf_pre[ki][kt][ks] = vv;
+                } else {
+                    kf_pre[ki][kt][ks] = row_frag<T>(kp, ld, key, P, 32 * ks + 8 * g);
+                    vf_pre[ki][kt][ks] = row_frag<T>(vp, ld, key, P, 32 * ks + 8 * g);
+                }
             }
+    if constexpr (FUSED) __syncthreads();              // all key rows are in registers: the images may be overwritten
     if constexpr (RES) {                               // every query / dO row and its statistics staged once
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, ldo, P, tid, img_rows);
+        if constexpr (FUSED) {
+            // from the registers of the dQ part (rows past P are zero fragments): no second read of q and dO
+#pragma unroll
+            for (int qi = 0; qi < NBLK; ++qi)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = qi * 128 + wave * 16 * U + 16 * u + r;
+                    if (row < img_rows) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            *reinterpret_cast<typename Mma<T>::frag*>(Qimg + row * LDI + 32 * ks + 8 * g) = keep->q[qi][u][ks];
+                            *reinterpret_cast<typename Mma<T>::frag*>(Dimg + row * LDI + 32 * ks + 8 * g) = keep->d[qi][u][ks];
+                        }
+                    }
+                }
+        } else {
+            stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, ldo, P, tid, img_rows);
+        }
         for (int q = tid; q < img_rows; q += 512 / U) {
             const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
             stat0[q] = st.x - __builtin_amdgcn_logf(st.y);       // exponent offset incl. log2(1/sum); +inf for padding
-            stat1[q] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
+            if constexpr (FUSED) { if (q >= P) stat1[q] = 0.f; }       // rows < P: written by the dQ part of this workgroup
+            else stat1[q] = q < P ? delta[((long)bf * P + q) * heads + h] : 0.f;
         }
         __syncthreads();
     }
@@ -704,6 +763,30 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
   }   // key blocks
 }
 
+template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
+__global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                            int P, int heads, float scale, long ldqkv, long ldo) {
+    sattn_dkv_body<T, DH, U, FP8, RES, false>(qkv, dout, lse, delta, dqkv, P, heads, scale, ldqkv, ldo);
+}
+
+// Both parts in ONE workgroup per (frame, head) (keys-resident form): dQ with K / V staged in LDS, a barrier, then dK / dV
+// with Q / dO staged over the same bytes.  The second part's operands were read by this CU microseconds earlier -- they
+// stay on the CU -- the wavefronts' own key rows are read from the K / V images before they are overwritten, the Q / dO
+// images are written from the row fragments the dQ part loaded -- and delta passes through LDS: every operand is read from
+// global memory once (HBM-side traffic 1.69 x -> 1.0 x of the algorithmic bytes), one launch instead of two.
+template <typename T, int DH, bool FP8 = false>
+__global__ __launch_bounds__(512) void sattn_bwd_fused_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                              const T* __restrict__ dout, const float* __restrict__ lse,
+                                                              T* __restrict__ dqkv, int P, int heads, float scale,
+                                                              long ldqkv, long ldo) {
+    SattnKeep<T, DH, 1, RES_CHUNKS> keep;
+    sattn_dq_body<T, DH, 1, FP8, true, true>(qkv, out, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
+    __syncthreads();                    // every wavefront is done with the K / V images
+    sattn_dkv_body<T, DH, 1, FP8, true, true>(qkv, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
+}
+
 // ------------------------------------------------------------------------------------------
 #define DISPATCH_DH(DHV, ...)                                   \
     do {                                                        \
@@ -761,6 +844,12 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, long ldqkv, const void* o
     if (BF <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
     if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
+    static const int fused = istvt_tune("ISTVT_SATTN_FUSED_BWD", 1);
+    if (fused && dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
+        DISPATCH_DH(dh, LAUNCH_RES((sattn_bwd_fused_kernel<bf16_t, DH>), true, (const bf16_t*)qkv, (const bf16_t*)out,
+                                   (const bf16_t*)dout, lse, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo));
+        return istvt_check_launch();
+    }
     if (dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
         DISPATCH_DH(dh, {
             LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, true>), false, (const bf16_t*)qkv, (const bf16_t*)out,
