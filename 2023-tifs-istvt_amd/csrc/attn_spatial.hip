@@ -904,6 +904,12 @@ extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const voi
     if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
+    static const int fused = istvt_tune("ISTVT_SATTN_FUSED_BWD", 1);
+    if (fused && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
+        DISPATCH_DH(dh, LAUNCH_RES((sattn_bwd_fused_kernel<bf16_t, DH, true>), true, (const bf16_t*)qkv, (const bf16_t*)out,
+                                   (const bf16_t*)dout, lse, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo));
+        return istvt_check_launch();
+    }
     if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
         DISPATCH_DH(dh, {
             LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, true>), false, (const bf16_t*)qkv, (const bf16_t*)out,
