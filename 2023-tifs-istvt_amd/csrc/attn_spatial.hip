@@ -184,9 +184,18 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
     const int inner = heads * DH;
     const long ld = ldqkv;
     const T* base = qkv + (long)bf * P * ld;
+#ifdef ISTVT_SATTN_DIAG
+    // diagnostic: every workgroup reads the operands of (frame 0, head 0) -- all cache hits: what the kernel takes
+    // when no operand comes from HBM (1: K and V, 2: also Q)
+    const T* base_kv = qkv;
+    const T* qp = (ISTVT_SATTN_DIAG >= 2 ? qkv : base + h * DH);
+    const T* kp = base_kv + inner;
+    const T* vp = base_kv + 2 * inner;
+#else
     const T* qp = base + h * DH;
     const T* kp = base + inner + h * DH;
     const T* vp = base + 2 * inner + h * DH;
+#endif
     const float c = scale * LOG2E;
     constexpr int NBLK = RES ? RES_CHUNKS : 1;
     // the query rows of EVERY block this wavefront will own are requested first: in RES mode their latency then hides
