@@ -143,6 +143,13 @@ def layernorm(dtype, D=728, M=1003, pad=False):
     dx2 = ops.layernorm_bwd(dy, x, mean, rstd, g, dg2, db2, dres=dres, pad=pad, dcol=dcol)
     e = max(e, relerr(dx2, dx), relerr(dg2, dg), relerr(db2, db),
             relerr(dcol - 1.0, (xd.grad + dres.double()).sum(0)))
+    # without the residual input (the kernel variants that stage two operands), with and without the column sums
+    dg3, db3 = torch.zeros_like(g), torch.zeros_like(b)
+    dx3 = ops.layernorm_bwd(dy, x, mean, rstd, g, dg3, db3, pad=pad)
+    dg4, db4, dcol4 = torch.zeros_like(g), torch.zeros_like(b), torch.zeros((D,), dtype=torch.float32, device=DEV)
+    dx4 = ops.layernorm_bwd(dy, x, mean, rstd, g, dg4, db4, pad=pad, dcol=dcol4)
+    e = max(e, relerr(dx3, xd.grad), relerr(dg3, gd.grad), relerr(db3, bd.grad), relerr(dx4, dx3), relerr(dg4, dg3),
+            relerr(dcol4, xd.grad.sum(0)))
     return e, TOL[dtype]
 
 
@@ -314,9 +321,15 @@ def all_checks():
         out.append(('tokens_padded_rows_%s' % tag, lambda dt=dt: tokens(dt, pad=True)))
         out.append(('layernorm_%s' % tag, lambda dt=dt: layernorm(dt)))
         out.append(('layernorm_d64_%s' % tag, lambda dt=dt: layernorm(dt, 64, 77)))
+        # the LDS-DMA backward's chunking: D = 512 (one full chunk), 520 (one lane of the second), 1024 (two full chunks);
+        # fewer rows than wavefronts; more rows than the ring warms up with
+        for D_, M_ in ((512, 333), (520, 1003), (1024, 129), (728, 3), (728, 70001)):
+            out.append(('layernorm_D%d_M%d_%s' % (D_, M_, tag), lambda dt=dt, D_=D_, M_=M_: layernorm(dt, D_, M_)))
         out.append(('layernorm_bwd_reproducible_%s' % tag, lambda dt=dt: layernorm_bwd_reproducible(dt)))
         out.append(('frame_diff_%s' % tag, lambda dt=dt: frame_diff(dt)))
-        for P, heads, dh in ((197, 8, 64), (37, 8, 64), (362, 2, 32), (362, 8, 64), (128, 2, 64)):
+        # (129 .. 256 keys: the keys-resident kernels incl. the fused backward -- smallest, 32-multiples, largest)
+        for P, heads, dh in ((197, 8, 64), (37, 8, 64), (362, 2, 32), (362, 8, 64), (128, 2, 64), (129, 2, 64), (160, 8, 64),
+                             (200, 2, 32), (224, 8, 64), (256, 2, 64)):
             out.append(('attn_spatial_P%d_h%d_d%d_%s' % (P, heads, dh, tag),
                         lambda dt=dt, P=P, heads=heads, dh=dh: attn_spatial(dt, 3, P, heads, dh)))
         for F, heads, dh in ((9, 8, 64), (5, 2, 32), (17, 8, 64), (7, 8, 64), (17, 2, 32)):
