@@ -539,6 +539,9 @@ __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in,
                                              int W, int C, const float* bnp, int relu, int tid) {
     constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
     constexpr int NIT = (NVEC + 255) / 256;
+#ifdef ISTVT_DW_CACHE_DIAG
+    f = 0; y0 = 0; x0 = 0;          // diagnostic: every workgroup stages the first tile (cache hits only)
+#endif
     // phase 1: issue every global load of the tile before touching any result (one dependent
     // load->LDS-store round per loop iteration made the tile fill a chain of HBM latencies)
     const int ch = tid % DW_NCH, c = c0 + ch * 8;          // 256 % DW_NCH == 0: same chunk every iteration
