@@ -74,7 +74,13 @@ __device__ __forceinline__ void slot_barrier() {
 // smaller than 2 GiB (32-bit buffer offsets).
 // DBG (diagnostic builds only, -DISTVT_GEMM_DIAG + ISTVT_GEMM_QDBG=n): 1 = no DMA inside the K loop, 2 = no MFMA,
 // 4 = no LDS fragment reads, 8 = s_memtime stamps of block 0 (tile start / K loop end / epilogue end) into C2, 16 / 32 = every
-// tile reads the FIRST A / B panel (all L2 hits: the staging rate without HBM misses), 128 = no output stores.
+// tile reads the FIRST A / B panel (all L2 hits: the staging rate without HBM misses), 128 = no output stores,
+// 256 = slot stamps: s_memtime at every boundary inside a K tile (DMA issued / fragment reads back / vmcnt wait over /
+// barrier passed / MFMAs issued / barrier passed, for both phases), summed per segment over all K tiles of the workgroup
+// in scalar registers, plus the s_memtime and s_memrealtime span of every K loop (in-kernel clock = cycles / ticks x
+// 100 MHz); every wavefront stores its 16 sums into C2 at [(workgroup * 8 + wavefront) * 16] once, at the end.  The
+// stamps' own lgkmcnt(0) puts the fragment reads in front of the vmcnt wait: read the SHARES, not the run time
+// (tools/gemm_slots.py; a stamp costs ~40 cycles, which every segment includes).
 // TM = rows of a C tile: 256, or 224 = AL unit (128 rows) + 96 rows of the AH unit (its last four DMA pieces are sent
 // out of range: no traffic, zeros in LDS, same instruction and vmcnt counts), phase B then runs 3 instead of 4 row tiles
 // (24 MFMA).  At M = 56 736 this turns 222 row tiles into 254: an N = 728 GEMM is 762 tiles = 2.98 rounds of 256 CUs of
@@ -268,6 +274,22 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         for (int j = 0; j < (STATS == 1 ? 8 : 1); ++j) st2[j] = 0.f;
     };
 
+    // DBG 256: per-segment cycle sums (wave-uniform, scalar registers)
+    unsigned seg[12];
+    unsigned long long t_prev = 0, clk_c = 0, clk_r = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) seg[j] = 0u;
+    auto stamp = [&](const int i, const bool open) {      // closes segment i - 1 (unless `open`: the first stamp of a tile)
+        if constexpr ((DBG & 256) != 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (!open) seg[(i + 11) % 12] += (unsigned)(t - t_prev);
+            t_prev = t;
+        }
+    };
+
     int KT = 0;                                // K tiles consumed so far (stream-wide): slot parity
     int U0 = 0;                                // first unit of the current K tile
     for (int ti = 0; ti < my_tiles; ++ti) {
@@ -311,6 +333,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         unsigned long long t_stamp[3];
         if (DBG & 8) t_stamp[0] = __builtin_amdgcn_s_memtime();
         if (wm == 1) slot_barrier();           // stagger: waves 4..7 run one slot behind inside the tile
+        unsigned long long k0_c = 0, k0_r = 0;
+        if constexpr ((DBG & 256) != 0) {
+            k0_c = __builtin_amdgcn_s_memtime(); k0_r = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
 
         auto ktile = [&](const bool first, const bool last) {
             const char* ubase = smem + (KT & 1) * 4 * QU_BYTES;
@@ -356,6 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             // load slot, and the loop is bound by how early these requests start -- and only then the fragment reads.
             // Needs the opaque DMA form (dma16_lds, gemm_shared.h): after the builtin the compiler drains vmcnt before
             // every LDS read.
+            stamp(0, first);
             if (DBG & 64) __builtin_amdgcn_s_setprio(1);
             if (first && p.bias) {
                 // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped);
@@ -365,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                          (unsigned)(__SIZE_TYPE__)(lds_void*)slab, (unsigned)(col * 4), 0);
             }
             if (ISTVT_Q_ORDER == 0) issue_pair(2);                           // units U0+6, U0+7
+            stamp(1, false);
             load_a(ua_lo, la_a, 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -377,19 +406,26 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 }
             }
             if (ISTVT_Q_ORDER == 1) issue_pair(2);
+            stamp(2, false);
             // unit U0+3 (AH) landed: all but the 4 younger units (8 pieces); fewer exist only when the stream ends
             if (total_u - 1 - (U0 + 3) >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else wait_vm_n(2 * max(0, total_u - 1 - (U0 + 3)));
             if (DBG & 64) __builtin_amdgcn_s_setprio(0);
+            stamp(3, false);
             slot_barrier();
+            stamp(4, false);
             mma(0, 4);
+            stamp(5, false);
             slot_barrier();
+            stamp(6, false);
             // ---- phase B: AH x B
             if (DBG & 64) __builtin_amdgcn_s_setprio(1);
             if (ISTVT_Q_ORDER == 0) issue_pair(0);                           // units U0+8, U0+9
+            stamp(7, false);
             load_a(ua_hi, la_h, NB);
             if (ISTVT_Q_ORDER == 1) issue_pair(0);
             if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
+            stamp(8, false);
             // units <= U0+6 (the next K tile's AL, BL, BH) landed; the side loads just issued are younger still
             if (total_u - 1 - (U0 + 6) >= 3) {
                 if (last && HAS_SIDE) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -398,9 +434,13 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 wait_vm_n(2 * max(0, total_u - 1 - (U0 + 6)) + ((last && HAS_SIDE) ? 4 : 0));
             }
             if (DBG & 64) __builtin_amdgcn_s_setprio(0);
+            stamp(9, false);
             slot_barrier();
+            stamp(10, false);
             mma(4, NB);
+            stamp(11, false);
             slot_barrier();
+            if (last) stamp(12, false);
             ++KT;
             U0 += 4;
         };
@@ -416,6 +456,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         }
         for (int s = 1; s < nkt - 1; ++s) ktile(false, false);
         if (nkt > 1) ktile(false, true);
+        if constexpr ((DBG & 256) != 0) {
+            const unsigned long long k1_c = __builtin_amdgcn_s_memtime(), k1_r = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            clk_c += k1_c - k0_c; clk_r += k1_r - k0_r;
+        }
 
         if (wm == 0) slot_barrier();           // re-align the two groups: both run the epilogue together
         if (DBG & 8) t_stamp[1] = __builtin_amdgcn_s_memtime();
@@ -519,4 +564,12 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         }
     }
     if constexpr (STATS != 0) stats_flush();
+    if constexpr ((DBG & 256) != 0) {
+        if (lane == 0) {
+            unsigned long long* d = (unsigned long long*)p.C2 + ((long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) d[j] = seg[j];
+            d[12] = clk_c; d[13] = clk_r; d[14] = (unsigned long long)my_tiles * nkt; d[15] = 1;
+        }
+    }
 }
