@@ -45,6 +45,33 @@
 #ifndef ISTVT_Q_ORDER
 #define ISTVT_Q_ORDER 0
 #endif
+// ISTVT_Q_SCHED: 0 = the schedule above (rounds 2-3).  1 = round 4, after the slot stamps (profiles/r04_a_*): a load slot
+// took 930 / 790 cycles against 520 of MFMA, ~400 of them the issue of the slot's 16 DMA pieces (the CU's address path
+// takes ~25 cycles per 1 KiB piece whoever issues it, with or without MFMAs or LDS reads beside it) and ~230 / ~100 the
+// fragment reads, and a wavefront's own DMA issue and LDS reads do not overlap in any order (reads first, interleaved, or
+// split over the wavefronts: same sum).  So the A fragments of phase A are read INSIDE the MFMA slot, between the MFMAs
+// (one ds_read_b128 per four MFMAs, two ahead), and a load slot carries four DMA pieces + eight fragment reads:
+//      L_A(k)   DMA AL(k+1), AH(k+1)    reads B(k) (8)            wait: AH(k) landed       vmcnt(8)
+//      C_A(k)   32 MFMA AL(k) x B(k), the 8 reads of AL(k) between them
+//      L_B(k)   DMA BL(k+2), BH(k+2)    reads AH(k) (8)           wait: B(k+1) landed      vmcnt(8)
+//      C_B(k)   32 MFMA AH(k) x B(k)                              wait: AL(k+1) landed     vmcnt(6)
+// Unit X(k) lives in ring slot 4 (k & 1) + {AL 0, BL 1, BH 2, AH 3}, k = the stream-wide K tile index.  With waves 4..7 one
+// slot behind (g1 = g0 + 1; g0's L_A(k) is slot 4k):
+//   * WAR: AL(k-1) is last read in g1's C_A(k-1) (slot 4k-2), AH(k-1) in g1's L_B(k-1) (4k-1): both before the barrier that
+//     opens g0's L_A(k) (4k), which overwrites them; B(k) is last read in g1's L_A(k) (4k+1), overwritten from g0's L_B(k) (4k+2).
+//   * RAW: a wavefront waits for its own pieces; every wavefront must have waited before the barrier that opens the first
+//     slot in which anybody reads the unit.  AH(k): waited at the end of L_A(k) (g0 4k, g1 4k+1), first read in g0's L_B(k)
+//     (4k+2).  B(k+1): waited at the end of L_B(k) (4k+2, 4k+3), first read in g0's L_A(k+1) (4k+4).  AL(k+1): waited at the
+//     end of C_B(k) (4k+3, 4k+4), first read in g0's C_A(k+1) (4k+5).
+//   * vmcnt: the issue order of a wavefront is ... AL(k), AH(k) | BL(k+1), BH(k+1) | AL(k+1), AH(k+1) | BL(k+2), BH(k+2) ...,
+//     two pieces each; after AH(k) come 8 pieces by the end of L_A(k), after BH(k+1) 8 by the end of L_B(k), after AL(k+1) 6
+//     by the end of C_B(k).  Past the end of the stream the producers keep issuing pieces that are out of range for every
+//     lane (no traffic, zeros into ring slots nobody reads), so the counts never change; anything else in flight
+//     (epilogue stores, side loads, the bias) only makes a wait cover more.  The kernel drains vmcnt before it ends.
+//   Every unit is requested >= 3 slots before its wait (round 3: BH 2 slots).
+#ifndef ISTVT_Q_SCHED
+#define ISTVT_Q_SCHED 1
+#endif
 
 constexpr int QU_BYTES = 16384;
 constexpr int QNU = 8;
@@ -78,9 +105,11 @@ __device__ __forceinline__ void slot_barrier() {
 // 256 = slot stamps: s_memtime at every boundary inside a K tile (DMA issued / fragment reads back / vmcnt wait over /
 // barrier passed / MFMAs issued / barrier passed, for both phases), summed per segment over all K tiles of the workgroup
 // in scalar registers, plus the s_memtime and s_memrealtime span of every K loop (in-kernel clock = cycles / ticks x
-// 100 MHz); every wavefront stores its 16 sums into C2 at [(workgroup * 8 + wavefront) * 16] once, at the end.  The
+// 100 MHz); every wavefront stores its sums (plus the epilogue's and
+// the tile-to-tile gap's cycles) into C2 at [(workgroup * 8 + wavefront) * 24] once, at the end.  The
 // stamps' own lgkmcnt(0) puts the fragment reads in front of the vmcnt wait: read the SHARES, not the run time
-// (tools/gemm_slots.py; a stamp costs ~40 cycles, which every segment includes).
+// (tools/gemm_slots.py; a stamp costs ~40 cycles, which every segment includes).  1024 = only the per-tile spans (K loop,
+// epilogue, tile-to-tile gap) and the clock, three stamps per tile: the K tile's time in an otherwise unperturbed kernel.
 // TM = rows of a C tile: 256, or 224 = AL unit (128 rows) + 96 rows of the AH unit (its last four DMA pieces are sent
 // out of range: no traffic, zeros in LDS, same instruction and vmcnt counts), phase B then runs 3 instead of 4 row tiles
 // (24 MFMA).  At M = 56 736 this turns 222 row tiles into 254: an N = 728 GEMM is 762 tiles = 2.98 rounds of 256 CUs of
@@ -129,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const int my_tiles = p.walk == 1 ? max(0, (snr * tiles_n - sj + sG - 1) / sG) : (nwg - (int)blockIdx.x + G - 1) / G;
     const int total_u = my_tiles * nkt * 4;
 
-    auto tile_origin = [&](int i, int& bm0, int& bn0) {
+    auto tile_origin_calc = [&](int i, int& bm0, int& bn0) {
         if (p.walk == 1) {
             const int e = sj + i * sG;
             const int bw = p.band > 0 ? min(p.band, tiles_n) : tiles_n, nb = (tiles_n + bw - 1) / bw;
@@ -138,9 +167,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             const int gm = p.gm > 0 ? p.gm : 1;
             const int grp = el / (gm * wb), idl = el - grp * gm * wb;
             const int rows_here = min(gm, snr - grp * gm);
-            // (integer division runs on the vector ALU: hand the results back as scalars, the DMA's scalar offsets need them)
-            bm0 = __builtin_amdgcn_readfirstlane((sr0 + grp * gm + idl % rows_here) * TM);
-            bn0 = __builtin_amdgcn_readfirstlane((b * bw + idl / rows_here) * T256);
+            bm0 = (sr0 + grp * gm + idl % rows_here) * TM;
+            bn0 = (b * bw + idl / rows_here) * T256;
             return;
         }
         int id = (int)blockIdx.x + i * G;
@@ -163,6 +191,23 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         const int rows_here = min(gm, tiles_m - grp * gm);
         bm0 = (grp * gm + idl % rows_here) * TM;
         bn0 = (idl / rows_here) * T256;
+    };
+    // The origins of this workgroup's first 64 tiles, one per lane, computed ONCE (all lanes at a time on the vector ALU) and
+    // looked up with v_readlane.  The walk's integer divisions cost ~400 instructions per call and used to run three times
+    // per tile inside the load slots and at the head of every tile: the r04 slot stamps showed ~125 cycles per load slot of
+    // this bookkeeping.
+    int tab_m, tab_n;
+    tile_origin_calc(lane, tab_m, tab_n);
+    auto tile_origin = [&](int i, int& bm0, int& bn0) {
+        if (i < 64) {
+            bm0 = __builtin_amdgcn_readlane(tab_m, i);
+            bn0 = __builtin_amdgcn_readlane(tab_n, i);
+        } else {
+            int m, n;
+            tile_origin_calc(i, m, n);
+            bm0 = __builtin_amdgcn_readfirstlane(m);
+            bn0 = __builtin_amdgcn_readfirstlane(n);
+        }
     };
 
     constexpr unsigned OOB = 0x80000000u, WINDOW = 0x7fffffffu, RSRC_FLAGS = 0x00020000u;
@@ -187,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.B), 0, p.N * ldb * 2, RSRC_FLAGS);
     int P = 0, p_s = 0, p_i = 0;
     int a_org = 0, b_org = 0;                     // byte offsets of the producer's tile inside A / B
+    int KTQ = 0;                                  // K tiles consumed so far (diagnostic builds: DBG 1 stops the DMA after the first)
     auto p_setup = [&](int i) {
         int bm0, bn0;
         tile_origin(i, bm0, bn0);
@@ -221,10 +267,53 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             if (++p_i < my_tiles) p_setup(p_i);
         }
     };
-    if (my_tiles > 0) p_setup(0);
-    issue_pair(0); issue_pair(2); issue_pair(0);           // units 0..5
-    wait_vm_n(min(6, 2 * max(0, total_u - 3)));            // units 0..2 landed (own pieces)
-    slot_barrier();
+    // ---- SCHED 1: an A-side and a B-side producer, each at its own K tile of the stream ----
+    constexpr int SCHED = ISTVT_Q_SCHED;
+    int pa_i = 0, pa_s = 0, pa_par = 0, pb_i = 0, pb_s = 0, pb_par = 0;
+    auto a_setup = [&](int i) { int bm0, bn0; tile_origin(i, bm0, bn0); a_org = (DBG & 16) ? 0 : bm0 * lda * 2; };
+    auto b_setup = [&](int i) { int bm0, bn0; tile_origin(i, bm0, bn0); b_org = (DBG & 32) ? 0 : bn0 * ldb * 2; };
+    const unsigned ring0 = (unsigned)(__SIZE_TYPE__)(lds_void*)smem + wave * 1024;
+    auto issue_a = [&](const int hi) {                 // the two pieces of AL (hi = 0) / AH (hi = 1) of the A producer's K tile
+        if ((DBG & 1) && KTQ >= 1) return;
+        if ((DBG & 512) && (wave & 3) != 0 && KTQ >= 1) return;      // timing probe: one wavefront in four issues DMA (wrong results)
+        const int k0 = pa_s * 64;
+        const unsigned dead = (pa_i >= my_tiles || chunk * 8 >= p.K - k0) ? OOB : 0u;
+        const int sa = a_org + k0 * 2 + (hi ? 128 * lda * 2 : 0);
+        const unsigned dst = ring0 + (pa_par * 4 + (hi ? 3 : 0)) * QU_BYTES;
+        dma16_lds(a_rs, dst, va[0] | dead, sa);
+        dma16_lds(a_rs, dst + 8192, va[1] | dead | (hi ? ah_dead : 0u), sa);
+    };
+    auto a_next = [&]() {
+        pa_par ^= 1;
+        if (++pa_s == nkt) { pa_s = 0; if (++pa_i < my_tiles) a_setup(pa_i); }
+    };
+    auto issue_b = [&](const int hi) {                 // BL (hi = 0) / BH (hi = 1) of the B producer's K tile
+        if ((DBG & 1) && KTQ >= 1) return;
+        if ((DBG & 512) && (wave & 3) != 0 && KTQ >= 1) return;      // timing probe: one wavefront in four issues DMA (wrong results)
+        const int k0 = pb_s * 64;
+        const unsigned dead = (pb_i >= my_tiles || chunk * 8 >= p.K - k0) ? OOB : 0u;
+        const int sb = b_org + k0 * 2 + (hi ? 128 * ldb * 2 : 0);
+        const unsigned dst = ring0 + (pb_par * 4 + 1 + hi) * QU_BYTES;
+        dma16_lds(b_rs, dst, vb[0] | dead, sb);
+        dma16_lds(b_rs, dst + 8192, vb[1] | dead, sb);
+    };
+    auto b_next = [&]() {
+        pb_par ^= 1;
+        if (++pb_s == nkt) { pb_s = 0; if (++pb_i < my_tiles) b_setup(pb_i); }
+    };
+    if constexpr (SCHED == 1) {
+        if (my_tiles > 0) { a_setup(0); b_setup(0); }
+        issue_b(0); issue_b(1); b_next();                  // B(0)
+        issue_a(0); issue_a(1); a_next();                  // AL(0), AH(0)
+        issue_b(0); issue_b(1); b_next();                  // B(1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // B(0), AL(0) landed (own pieces)
+        slot_barrier();
+    } else {
+        if (my_tiles > 0) p_setup(0);
+        issue_pair(0); issue_pair(2); issue_pair(0);           // units 0..5
+        wait_vm_n(min(6, 2 * max(0, total_u - 3)));            // units 0..2 landed (own pieces)
+        slot_barrier();
+    }
 
     float* slab = reinterpret_cast<float*>(smem + QNU * QU_BYTES + wave * PSLAB_BYTES);
     const float alpha = p.alpha;
@@ -276,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 
     // DBG 256: per-segment cycle sums (wave-uniform, scalar registers)
     unsigned seg[12];
-    unsigned long long t_prev = 0, clk_c = 0, clk_r = 0;
+    unsigned long long t_prev = 0, clk_c = 0, clk_r = 0, ep_c = 0, gap_c = 0, t_ep_end = 0;
 #pragma unroll
     for (int j = 0; j < 12; ++j) seg[j] = 0u;
     auto stamp = [&](const int i, const bool open) {      // closes segment i - 1 (unless `open`: the first stamp of a tile)
@@ -334,12 +423,105 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         if (DBG & 8) t_stamp[0] = __builtin_amdgcn_s_memtime();
         if (wm == 1) slot_barrier();           // stagger: waves 4..7 run one slot behind inside the tile
         unsigned long long k0_c = 0, k0_r = 0;
-        if constexpr ((DBG & 256) != 0) {
+        if constexpr ((DBG & 1280) != 0) {
             k0_c = __builtin_amdgcn_s_memtime(); k0_r = __builtin_amdgcn_s_memrealtime();
             __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (ti > 0) gap_c += k0_c - t_ep_end;
         }
 
-        auto ktile = [&](const bool first, const bool last) {
+        auto ktile1 = [&](const bool first, const bool last) {
+            const char* ubase = smem + (KT & 1) * 4 * QU_BYTES;
+            const char* ua_lo = ubase;
+            const char* ua_hi = ubase + 3 * QU_BYTES;
+            const char* ub = ubase + b_unit * QU_BYTES;
+            bf16x8 af[4][2], bq[4][2];
+            auto rd = [&](const char* q, const int tag) -> bf16x8 {
+                if (DBG & 4) return __builtin_bit_cast(bf16x8, make_uint4(KT + tag, lane, tag, 1));
+                return *reinterpret_cast<const bf16x8*>(q);
+            };
+            auto mma4 = [&](const int mt, const int t, const int kh) {
+                if (DBG & 2) { asm volatile("" ::"v"(af[t][kh])); asm volatile("" ::"v"(bq[t][kh])); return; }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt][nt], 0, 0, 0);
+            };
+            // ---- L_A: DMA AL(k+1), AH(k+1); the B fragments of this K tile
+            stamp(0, first);
+            if (first && p.bias) {
+                // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped); it is
+                // older than the 8 pieces of this K tile's two load slots, so the wait that closes L_B covers it
+                const int col = min(bn0 + wn * 64 + lane, p.N - 1);
+                dma4_lds(__builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.bias), 0, p.N * 4, RSRC_FLAGS),
+                         (unsigned)(__SIZE_TYPE__)(lds_void*)slab, (unsigned)(col * 4), 0);
+            }
+            issue_a(0); issue_a(1); a_next();
+            stamp(1, false);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bq[t][0] = rd(ub + la_b[0] + t * 2048, t);
+                bq[t][1] = rd(ub + la_b[1] + t * 2048, t + 4);
+            }
+            stamp(2, false);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // AH(k) landed
+            stamp(3, false);
+            slot_barrier();
+            stamp(4, false);
+            // ---- C_A: AL x B, the A fragments read between the MFMAs (fragment i: t = i & 3, kh = i >> 2), two ahead
+            af[0][0] = rd(ua_lo + la_a[0], 8);
+            af[1][0] = rd(ua_lo + la_a[0] + 2048, 9);
+#define QSTEP(i)                                                                                                        \
+            if ((i) + 2 < 8) af[((i) + 2) & 3][((i) + 2) >> 2] = rd(ua_lo + la_a[((i) + 2) >> 2] + (((i) + 2) & 3) * 2048, 10 + (i)); \
+            mma4((i) & 3, (i) & 3, (i) >> 2);
+            QSTEP(0) QSTEP(1) QSTEP(2) QSTEP(3) QSTEP(4) QSTEP(5) QSTEP(6) QSTEP(7)
+#undef QSTEP
+            if (!(DBG & 6)) {
+                // the order the scheduler is to emit: 3 reads, then 4 MFMAs + 1 read five times, then the MFMAs left
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            stamp(5, false);
+            slot_barrier();
+            stamp(6, false);
+            // ---- L_B: DMA BL(k+2), BH(k+2); the fragments of AH
+            issue_b(0); issue_b(1); b_next();
+            stamp(7, false);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t >= NB) continue;
+                af[t][0] = rd(ua_hi + la_h[0] + t * 2048, 20 + t);
+                af[t][1] = rd(ua_hi + la_h[1] + t * 2048, 24 + t);
+            }
+            if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
+            stamp(8, false);
+            // B(k+1) landed; the side loads just issued are younger still
+            if (last && HAS_SIDE) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            stamp(9, false);
+            slot_barrier();
+            stamp(10, false);
+            // ---- C_B: AH x B
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t >= NB) continue;
+                    mma4(4 + t, t, kh);
+                }
+            // AL(k+1) landed
+            if (last && HAS_SIDE) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            stamp(11, false);
+            slot_barrier();
+            if (last) stamp(12, false);
+            ++KT;
+            ++KTQ;
+        };
+        auto ktile0 = [&](const bool first, const bool last) {
             const char* ubase = smem + (KT & 1) * 4 * QU_BYTES;
             const char* ua_lo = ubase;
             const char* ua_hi = ubase + 3 * QU_BYTES;
@@ -444,6 +626,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             ++KT;
             U0 += 4;
         };
+#if ISTVT_Q_SCHED == 1
+#define ktile ktile1
+#else
+#define ktile ktile0
+#endif
         ktile(true, nkt == 1);
         if (p.bias) {
             // the bias DMA was issued in phase A of the first K tile, before units U0-4+6..9: phase B's wait covered it
@@ -456,10 +643,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         }
         for (int s = 1; s < nkt - 1; ++s) ktile(false, false);
         if (nkt > 1) ktile(false, true);
-        if constexpr ((DBG & 256) != 0) {
+        if constexpr ((DBG & 1280) != 0) {
             const unsigned long long k1_c = __builtin_amdgcn_s_memtime(), k1_r = __builtin_amdgcn_s_memrealtime();
             __builtin_amdgcn_s_waitcnt(0xC07F);
             clk_c += k1_c - k0_c; clk_r += k1_r - k0_r;
+            t_ep_end = k1_c;                    // (the epilogue's start; overwritten by its end below)
         }
 
         if (wm == 0) slot_barrier();           // re-align the two groups: both run the epilogue together
@@ -554,6 +742,13 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         }
 #undef QRB
+        if constexpr ((DBG & 1280) != 0) {
+            // the epilogue as the wavefront sees it: its last store ISSUED (no drain: the stores retire under the next tile)
+            const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            ep_c += e1 - t_ep_end;
+            t_ep_end = e1;
+        }
         if (DBG & 8) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             t_stamp[2] = __builtin_amdgcn_s_memtime();
@@ -564,12 +759,14 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         }
     }
     if constexpr (STATS != 0) stats_flush();
-    if constexpr ((DBG & 256) != 0) {
+    if constexpr (SCHED == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the out-of-range pieces past the stream's end
+    if constexpr ((DBG & 1280) != 0) {
         if (lane == 0) {
-            unsigned long long* d = (unsigned long long*)p.C2 + ((long)blockIdx.x * 8 + wave) * 16;
+            unsigned long long* d = (unsigned long long*)p.C2 + ((long)blockIdx.x * 8 + wave) * 24;
 #pragma unroll
             for (int j = 0; j < 12; ++j) d[j] = seg[j];
             d[12] = clk_c; d[13] = clk_r; d[14] = (unsigned long long)my_tiles * nkt; d[15] = 1;
+            d[16] = ep_c; d[17] = gap_c; d[18] = my_tiles;
         }
     }
 }

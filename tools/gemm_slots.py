@@ -38,7 +38,7 @@ def rnd(r, c):
 for K, N in shapes:
     x, w = rnd(M, K), rnd(N, K)
     y = ops.empty_rows(M, N, dt, x.device, True)
-    dbg = torch.zeros(256 * 8 * 16, device='cuda', dtype=torch.int64)
+    dbg = torch.zeros(256 * 8 * 24, device='cuda', dtype=torch.int64)
     lda, ldb, ldc = x.stride(0), w.stride(0), y.stride(0)
 
     def fn():
@@ -57,7 +57,7 @@ for K, N in shapes:
         fn()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    d = dbg.cpu().view(256, 8, 16).double()
+    d = dbg.cpu().view(256, 8, 24).double()
     live = d[:, 0, 15] > 0
     d = d[live]
     G = d.shape[0]
@@ -70,6 +70,12 @@ for K, N in shapes:
     print('in-kernel clock (median over workgroups and wavefronts): %.3f GHz   [min %.3f max %.3f]' %
           (float(clk.median()), float(clk.min()), float(clk.max())))
     print('K tile, stamped build: %.0f cycles = %.3f us' % (float(loop.median()), float(loop.median() / clk.median() * 1e-3)))
+    tiles = d[:, :, 18].clamp(min=1)
+    ep = (d[:, :, 16] / tiles).median()
+    gap = (d[:, :, 17] / (tiles - 1).clamp(min=1)).median()
+    kl = (d[:, :, 12] / tiles).median()
+    print('per tile: K loop %.0f cycles, epilogue (to its last store issued) %.0f, epilogue end -> next K loop %.0f  [K loop share %.1f %%]'
+          % (float(kl), float(ep), float(gap), 100.0 * float(kl / (kl + ep + gap))))
     for grp, name in ((slice(0, 4), 'waves 0-3 (leading group)'), (slice(4, 8), 'waves 4-7 (one slot behind)')):
         med = per[:, grp, :].reshape(-1, 12).median(0).values
         print('  %s: cycles per K tile, median' % name)
@@ -78,4 +84,8 @@ for K, N in shapes:
         la, ca = float(med[0:4].sum()), float(med[4:6].sum())
         lb, cb = float(med[6:10].sum()), float(med[10:12].sum())
         print('    load slot A %5.0f | mfma slot A %5.0f | load slot B %5.0f | mfma slot B %5.0f | sum %6.0f' % (la, ca, lb, cb, la + ca + lb + cb))
+    if os.environ.get('GS_PER_WAVE'):
+        for wv in range(8):
+            med = per[:, wv, :].median(0).values
+            print('  wave %d: %s' % (wv, ' '.join('%5.0f' % float(v) for v in med)))
     sys.stdout.flush()
