@@ -17,6 +17,7 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     'istvt_gemm': [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, I, I, I, F, P, P, I, I, P],
     'istvt_layernorm_fwd': [P, L, P, P, P, L, P, P, L, I, F, I, P],
+    'istvt_layernorm_fwd_diff': [P, L, P, P, P, L, P, L, P, P, I, I, I, I, F, I, P],
     'istvt_layernorm_bwd': [P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, L, L, I, I, P],
     'istvt_layernorm_bwd_ws_elems': [L, I],
     'istvt_attn_spatial_fwd': [P, L, P, L, P, I, I, I, I, F, I, P],

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void tattn_bwd2_kernel(const T* __restrict__ q
 
 extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, long ldv, void* out, long ldo, int B, int F,
                                        int P, int heads, int dh, float scale, int diff, int dtype, hipStream_t stream) {
-    if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (B <= 0 || F <= 0 || P <= 0 || heads <= 0 || diff < 0 || diff > 2) return ISTVT_ERR_SHAPE;
     if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldo < (long)heads * dh || ldqk % 8 || ldv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     static const int use_mfma = istvt_tune("ISTVT_TATTN_MFMA", 1);
     if (use_mfma && dtype == DT_BF16 && F <= 32 && (dh == 64 || dh == 32)) {     // one wavefront per (b, p, h), MFMA tiles
@@ -543,6 +543,7 @@ extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v,
 #undef TATTN_F
         return istvt_check_launch();
     }
+    if (diff == 2) return ISTVT_ERR_SHAPE;      // pre-differenced operands: the bfloat16 MFMA kernels only
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_fwd_kernel, tattn_fwd2_kernel, (const T*)qk, (const T*)v, (T*)out, B, F, P,
                                          heads, scale, ldqk, ldv, ldo, diff));
     return istvt_check_launch();
@@ -551,7 +552,7 @@ extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v,
 extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, long ldv, const void* dout, long ldo,
                                        void* dqk, void* dv, int B, int F, int P, int heads, int dh, float scale, int diff,
                                        int dtype, hipStream_t stream) {
-    if (B <= 0 || F <= 0 || P <= 0 || heads <= 0) return ISTVT_ERR_SHAPE;
+    if (B <= 0 || F <= 0 || P <= 0 || heads <= 0 || diff < 0 || diff > 2) return ISTVT_ERR_SHAPE;
     if (ldqk < 2L * heads * dh || ldv < (long)heads * dh || ldo < (long)heads * dh || ldqk % 8 || ldv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     static const int use_mfma = istvt_tune("ISTVT_TATTN_MFMA", 1);
     // measured at C2 / C4 (tools/tattn_bench.py): F = 9 lane-cluster 170 us vs MFMA 203 us (its three 32-row LDS images
@@ -569,6 +570,7 @@ extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v,
 #undef TATTN_B
         return istvt_check_launch();
     }
+    if (diff == 2) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, DISPATCH_TATTN(tattn_bwd_kernel, tattn_bwd2_kernel, (const T*)qk, (const T*)v, (const T*)dout,
                                          (T*)dqk, (T*)dv, B, F, P, heads, scale, ldqk, ldv, ldo, diff));
     return istvt_check_launch();

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) tmf::mma(s[t][u], kf[t][ks], qf[u][ks]);
         }
-    if (diff) {                                            // S' = D S D^T (see the helpers above)
+    if (diff == 1) {                                       // S' = D S D^T (see the helpers above)
         tmf::diff_lanes<NTL, NTL>(s, r);
         tmf::diff_rows<NTL, NTL>(s, lane);
     }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
                     tmf::mma(dp[t][u], vf[t][ks], dof[u][ks]);
                 }
             }
-        if (diff) {
+        if (diff == 1) {
             tmf::diff_lanes<NTL, NTL>(s, r);
             tmf::diff_rows<NTL, NTL>(s, lane);
         }
@@ -384,20 +384,26 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
                 for (int j = 0; j < 4; ++j) s[t][u][j] = s[t][u][j] * (dp[t][u][j] - dl) * scale;      // dS'^T (query rows >= F: dO = 0 -> 0)
             if (g == 0) { st[0][q] = mx; st[1][q] = inv; st[2][q] = dl; }                           // rows q >= F: never used (p = 0 there)
         }
-        if (diff) {                                        // dS = D^T dS' D: the gradient w.r.t. the UN-differenced scores
+        if (diff == 1) {                                   // dS = D^T dS' D: the gradient w.r.t. the UN-differenced scores
             tmf::adj_lanes<NTL, NTL>(s, r);
             tmf::adj_rows<NTL, NTL>(s, lane);
         }
 #pragma unroll
-        for (int u = 0; u < NTL; ++u) {
-            if (16 * u >= F) break;
-            const int q = 16 * u + r;
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 dq[1][NTL];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                f32x4 dq = f32x4{0, 0, 0, 0};
-                tmf::mma_frames<NTL>(dq, Kimg, LDI, 16 * dt, g, r, s[0][u], s[NTL - 1][u]);
+            for (int u = 0; u < NTL; ++u) {
+                dq[0][u] = f32x4{0, 0, 0, 0};
+                if (16 * u < F) tmf::mma_frames<NTL>(dq[0][u], Kimg, LDI, 16 * dt, g, r, s[0][u], s[NTL - 1][u]);
+            }
+            // diff == 2: q', k' arrived differenced (K' is what the images hold), dQ' = dS' K' is the gradient w.r.t. q';
+            // the caller wants it w.r.t. the un-differenced projection: dQ = D^T dQ' along the frames (= the lanes here)
+            if (diff == 2) tmf::adj_lanes<1, NTL>(dq, r);
+#pragma unroll
+            for (int u = 0; u < NTL; ++u) {
+                const int q = 16 * u + r;
                 if (q < F) {
-                    float o[4] = {dq[0], dq[1], dq[2], dq[3]};
+                    float o[4] = {dq[0][u][0], dq[0][u][1], dq[0][u][2], dq[0][u][3]};
                     store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
                 }
             }
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
                     tmf::mma(dp[tt][kt], dof[tt][ks], vf[kt][ks]);
                 }
             }
-        if (diff) {
+        if (diff == 1) {
             tmf::diff_lanes<NTL, NTL>(s, r);
             tmf::diff_rows<NTL, NTL>(s, lane);
         }
@@ -440,23 +446,33 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
                     dp[tt][kt][j] = pv * (dp[tt][kt][j] - dv4[j]) * scale;        // dS'
                 }
         }
-        if (diff) {
+        if (diff == 1) {
             tmf::adj_lanes<NTL, NTL>(dp, r);
             tmf::adj_rows<NTL, NTL>(dp, lane);
         }
 #pragma unroll
-        for (int kt = 0; kt < NTL; ++kt) {
-            if (16 * kt >= F) break;
-            const int key = 16 * kt + r;
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 dkk[1][NTL];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                f32x4 dvv = f32x4{0, 0, 0, 0}, dkk = f32x4{0, 0, 0, 0};
+            for (int kt = 0; kt < NTL; ++kt) {
+                dkk[0][kt] = f32x4{0, 0, 0, 0};
+                if (16 * kt >= F) continue;
+                f32x4 dvv = f32x4{0, 0, 0, 0};
                 tmf::mma_frames<NTL>(dvv, Dimg, LDI, 16 * dt, g, r, s[0][kt], s[NTL - 1][kt]);
-                tmf::mma_frames<NTL>(dkk, Qimg, LDI, 16 * dt, g, r, dp[0][kt], dp[NTL - 1][kt]);
+                tmf::mma_frames<NTL>(dkk[0][kt], Qimg, LDI, 16 * dt, g, r, dp[0][kt], dp[NTL - 1][kt]);
+                const int key = 16 * kt + r;
                 if (key < F) {
-                    float a[4] = {dkk[0], dkk[1], dkk[2], dkk[3]}, bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
-                    store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
+                    float bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
                     store4(dvp + (long)key * sv + 16 * dt + 4 * g, bb);
+                }
+            }
+            if (diff == 2) tmf::adj_lanes<1, NTL>(dkk, r);         // dK = D^T dK' (see dQ above)
+#pragma unroll
+            for (int kt = 0; kt < NTL; ++kt) {
+                const int key = 16 * kt + r;
+                if (key < F) {
+                    float a[4] = {dkk[0][kt][0], dkk[0][kt][1], dkk[0][kt][2], dkk[0][kt][3]};
+                    store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
                 }
             }
         }

@@ -40,6 +40,8 @@ struct GemmArgs {
     double* st_sum;       // gemm256q<.., STATS = 1>: per-column sum / sum of squares of the STORED outputs, replica 0's rows
     double* st_sumsq;     //   (double[R][2][N] accumulators of stem.hip; train-mode BatchNorm statistics of a 1x1 conv)
                           // gemm256q<.., STATS = 2>: st_sum only (a bias gradient; folded by istvt_stats_reduce_add)
+    int a_sel_col;        // gemm256q: > 0: column tiles at or past this column take their A rows from a SECOND plane,
+    int a2_off;           //   a2_off bytes behind A (istvt_gemm flags bit 1: the plane follows the first one, M rows of lda)
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -317,6 +319,13 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
     a.st_sum = col_sum; a.st_sumsq = col_sumsq;
     a.blocked = flags & 1;
+    const bool a_sel = (flags & 2) != 0;
+    if (a_sel) {
+        a.a_sel_col = ((flags >> 16) & 0xffff) * 64;
+        a.a2_off = (int)((long)M * lda * 2);
+        if (a.a_sel_col <= 0 || a.a_sel_col % T256 != 0 || a.a_sel_col >= N || dtype != DT_BF16 || !a_kc ||
+            2 * (long)M * lda * 2 >= 0x7fffffffL) return ISTVT_ERR_SHAPE;
+    }
     if (col_sumsq && !col_sum) return ISTVT_ERR_SHAPE;
     a.gm = 4;             // sweep at the model's shapes: 4 row-panels per tile group is best or neutral everywhere
     {
@@ -344,7 +353,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
         (a_kc ? (K % 8 == 0) : (M % 8 == 0 && N % 8 == 0))) {
         const int tiles = ((M + T256 - 1) / T256) * ((N + T256 - 1) / T256);
         const dim3 block(512);
-        const bool q_ok = a_kc && (long)M * lda * 2 < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K >= 32 &&
+        const bool q_ok = a_kc && (long)M * lda * 2 * (a_sel ? 2 : 1) < 0x7fffffffL && (long)N * ldb * 2 < 0x7fffffffL && K >= 32 &&
                           out_mode == 0 && splitk == 1 && (!bias || alpha == 1.0f) && !(epi != EPI_NONE && residual);
         const bool t_ok = !a_kc && out_mode == 3 && !bias && !residual && epi == EPI_NONE &&
                           (long)K * lda * 2 < 0x7fffffffL && (long)K * ldb * 2 < 0x7fffffffL;
@@ -440,13 +449,14 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             else hipLaunchKernelGGL((gemm256q_kernel<0, false>), grid, block, 0, stream, a);
             return istvt_check_launch();
         }
+        if (a_sel) return ISTVT_ERR_SHAPE;          // only the persistent NT kernel selects its A plane by column tile
         if (t_ok && !col_sum) {
             // weight gradient: unit / ping-pong structure with transposing fragment reads (gemm256t.h)
             hipLaunchKernelGGL(gemm256t_kernel, dim3(tiles * splitk), block, 0, stream, a);
             return istvt_check_launch();
         }
     }
-    if (col_sum) return ISTVT_ERR_SHAPE;        // only the persistent NT kernel accumulates statistics: the host checks first
+    if (col_sum || a_sel) return ISTVT_ERR_SHAPE;   // only the persistent NT kernel accumulates statistics / selects A planes: the host checks first
     DISPATCH_DTYPE(dtype, return launch_gemm<T>(a, a_kc, b_kc, splitk, stream));
     return ISTVT_OK;
 }

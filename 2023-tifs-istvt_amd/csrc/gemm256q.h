@@ -228,7 +228,9 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         va[i] = (unsigned)((hr0 + 64 * i) * lda * 2 + chunk * 16);
         vb[i] = (unsigned)((hr0 + 64 * i) * ldb * 2 + chunk * 16);
     }
-    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.A), 0, p.M * lda * 2, RSRC_FLAGS);
+    // (p.a_sel_col > 0: two planes of M rows; a row past M of the first plane then reads the second plane's first rows
+    //  instead of zeros -- it only reaches output rows past M, which are never stored)
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.A), 0, p.M * lda * 2 + (p.a_sel_col > 0 ? p.a2_off : 0), RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.B), 0, p.N * ldb * 2, RSRC_FLAGS);
     int P = 0, p_s = 0, p_i = 0;
     int a_org = 0, b_org = 0;                     // byte offsets of the producer's tile inside A / B
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     auto p_setup = [&](int i) {
         int bm0, bn0;
         tile_origin(i, bm0, bn0);
-        a_org = (DBG & 16) ? 0 : bm0 * lda * 2;        // DBG 16 / 32: every tile streams the first A / B panel (L2 hits only)
+        a_org = (DBG & 16) ? 0 : bm0 * lda * 2 + ((p.a_sel_col > 0 && bn0 >= p.a_sel_col) ? p.a2_off : 0);        // DBG 16 / 32: every tile streams the first A / B panel (L2 hits only)
         b_org = (DBG & 32) ? 0 : bn0 * ldb * 2;
     };
     // units P, P+1 of K tile p_s: J0 = 0 -> (AL, BL), J0 = 2 -> (BH, AH)
@@ -270,7 +272,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     // ---- SCHED 1: an A-side and a B-side producer, each at its own K tile of the stream ----
     constexpr int SCHED = ISTVT_Q_SCHED;
     int pa_i = 0, pa_s = 0, pa_par = 0, pb_i = 0, pb_s = 0, pb_par = 0;
-    auto a_setup = [&](int i) { int bm0, bn0; tile_origin(i, bm0, bn0); a_org = (DBG & 16) ? 0 : bm0 * lda * 2; };
+    auto a_setup = [&](int i) {
+        int bm0, bn0;
+        tile_origin(i, bm0, bn0);
+        a_org = (DBG & 16) ? 0 : bm0 * lda * 2 + ((p.a_sel_col > 0 && bn0 >= p.a_sel_col) ? p.a2_off : 0);
+    };
     auto b_setup = [&](int i) { int bm0, bn0; tile_origin(i, bm0, bn0); b_org = (DBG & 32) ? 0 : bn0 * ldb * 2; };
     const unsigned ring0 = (unsigned)(__SIZE_TYPE__)(lds_void*)smem + wave * 1024;
     auto issue_a = [&](const int hi) {                 // the two pieces of AL (hi = 0) / AH (hi = 1) of the A producer's K tile

@@ -5,8 +5,14 @@
 // lane access), mean and variance are two wave reductions (two-pass, fp32), gamma/beta are fp32.
 // HBM-bound: algorithmic traffic = one read + one write of the row (forward).
 //
-// (The frame difference of module.py:193 is not taken here: TemporalResidualAttention projects the LayerNorm output
-// once and the temporal attention kernels difference q and k, see attn_temporal.hip.)
+// ln_fwd_diff (bfloat16 path of TemporalResidualAttention, round 4): also writes the frame difference of module.py:193,
+//   diff[b,f,p] = y[b,f,p] (f < 2),  y[b,f,p] - y[b,f-1,p] (f >= 2),
+// taken in fp32 BEFORE the rounding to the storage type: the q / k projection then sees operands rounded at the
+// magnitude of the difference, as the reference's own order of operations does.  (Rounds 2-3 projected the
+// un-differenced rows and differenced bf16 q / k afterwards: for correlated consecutive frames -- what a face video
+// is -- the rounding error then scales with |q| instead of |q'|, 11 % of q' at a 3 % frame difference.)  One wavefront
+// walks the F frames of a position and keeps the previous normalised row in registers.  float32 keeps the in-kernel
+// difference of attn_temporal.hip (no rounding to lose).
 #include "common.h"
 #include <cstdlib>
 
@@ -92,6 +98,67 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             }
         }
         if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+    }
+}
+
+// forward, temporal variant: one wavefront per (b, p) walks f = 0..F-1; rows at (b*F + f)*P + p
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          T* __restrict__ diff, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, int Bn, int F, int P, int D,
+                                                          float eps, long ldx, long ldy, long ldd) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    float gm[LN_MAXCH][8], bt[LN_MAXCH][8];
+    ln_row_load<float>(gamma, D, lane, gm);
+    ln_row_load<float>(beta, D, lane, bt);
+    const long npos = (long)Bn * P;
+    // the next row of the walk (next frame, or frame 0 of this wavefront's next position) is requested before the
+    // current one is reduced (see ln_fwd_kernel)
+    typename Mma<T>::frag nxt[LN_MAXCH];
+    auto fetch = [&](long m) {
+#pragma unroll
+        for (int c = 0; c < LN_MAXCH; ++c) {
+            const int e = (lane + 64 * c) * 8;
+            if (e < D) nxt[c] = frag_load(x + m * ldx + e);
+        }
+    };
+    if (wave < npos) fetch(((wave / P) * F) * P + wave % P);
+    for (long w = wave; w < npos; w += nwaves) {
+        const long b = w / P, pp = w % P;
+        float prev[LN_MAXCH][8];
+        for (int f = 0; f < F; ++f) {
+            const long m = (b * F + f) * P + pp;
+            float v[LN_MAXCH][8];
+#pragma unroll
+            for (int c = 0; c < LN_MAXCH; ++c) {
+                const int e = (lane + 64 * c) * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[c][i] = e < D ? Mma<T>::get(nxt[c], i) : 0.f;
+            }
+            if (f + 1 < F) fetch(m + P);
+            else if (w + nwaves < npos) fetch((((w + nwaves) / P) * F) * P + (w + nwaves) % P);
+            float mean, rstd;
+            ln_stats(v, D, lane, eps, mean, rstd);
+#pragma unroll
+            for (int c = 0; c < LN_MAXCH; ++c) {
+                const int e = (lane + 64 * c) * 8;
+                if (e < D) {
+                    float o[8], dd[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        o[i] = (v[c][i] - mean) * rstd * gm[c][i] + bt[c][i];
+                        dd[i] = (f >= 2) ? o[i] - prev[c][i] : o[i];
+                        prev[c][i] = o[i];
+                    }
+                    store8(y + m * ldy + e, o);
+                    store8(diff + m * ldd + e, dd);
+                }
+            }
+            if (lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+        }
     }
 }
 
@@ -401,6 +468,18 @@ extern "C" int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, 
     if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0 || ldx < D || ldy < D || ldx % 8 || ldy % 8) return ISTVT_ERR_SHAPE;
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x,
                                              gamma, beta, (T*)y, mean, rstd, M, D, eps, ldx, ldy));
+    return istvt_check_launch();
+}
+
+// y and diff (see ln_fwd_diff_kernel): rows ordered (b, f, p), B clips x F frames x P positions
+extern "C" int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                        void* diff, long ldd, float* mean, float* rstd, int B, int F, int P, int D,
+                                        float eps, int dtype, hipStream_t stream) {
+    if (D % 8 != 0 || D > LN_MAXCH * 512 || B <= 0 || F <= 0 || P <= 0) return ISTVT_ERR_SHAPE;
+    if (ldx < D || ldy < D || ldd < D || ldx % 8 || ldy % 8 || ldd % 8) return ISTVT_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_diff_kernel<T>), dim3(ln_grid((long)B * P)), dim3(256), 0, stream,
+                                             (const T*)x, gamma, beta, (T*)y, (T*)diff, mean, rstd, B, F, P, D, eps, ldx,
+                                             ldy, ldd));
     return istvt_check_launch();
 }
 

@@ -77,6 +77,41 @@ class LayerNormFn(Function):
         return dx, rg, rb, None, None, None
 
 
+class LayerNormDiffFn(Function):
+    """LayerNorm + the frame difference of module.py:193 in one kernel (bfloat16 path of TemporalResidualAttention):
+    returns (y, diff[, x]) with diff = cat(y[:, :2], y[:, 2:] - y[:, 1:-1]) over frames, taken in fp32 before the rounding
+    to bfloat16.  y and diff are the two planes of one buffer (ops.layernorm_fwd_diff).  diff carries NO gradient of its
+    own: its only consumer, LinearCatSelFn + TemporalAttnFn(diff=2), returns the gradient of the whole
+    difference-project-attend chain with respect to y (the attention backward applies the difference's adjoint to dq and
+    dk), so the backward here is the plain LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, geom, fork=False, sink=None):
+        B, F, P = geom
+        x2 = x.reshape(-1, x.shape[-1])
+        y, yd, mean, rstd = ops.layernorm_fwd_diff(x2, gamma, beta, eps, B, F, P)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.set_materialize_grads(False)
+        ctx.sink = sink
+        ctx.mark_non_differentiable(yd)
+        y, yd = y.view(*x.shape), yd.view(*x.shape)
+        return (y, yd, x.view_as(x)) if fork else (y, yd)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dyd=None, dres=None):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dcol = ctx.sink.buffer() if ctx.sink is not None else None
+        if dy is None:
+            if dcol is not None and dres is not None:
+                ops.colsum(dres.reshape(-1, dres.shape[-1]), out=dcol)
+            return dres, None, None, None, None, None, None
+        dg, rg = _target(gamma)
+        db, rb = _target(beta)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True, dcol=dcol)
+        return dx, rg, rb, None, None, None, None
+
+
 class FrameDiffFn(Function):
     """residual = cat(x[:, :2], x[:, 2:] - x[:, 1:-1]) over frames (module.py:193) as a pass of its own.  The model does
     not use it (TemporalResidualAttention differences q and k inside the attention kernels); it is the reference-order
@@ -324,6 +359,39 @@ class LinearCatFn(Function):
         return (dx, *grads)
 
 
+class LinearCatSelFn(Function):
+    """LinearCatFn whose leading `sel_col` output columns are projections of a SECOND input xd that sits one plane in
+    front of x in memory (LayerNormDiffFn's two outputs): q | k = to_qk(diff), v = to_v(x) as ONE GEMM whose A operand is
+    picked per column tile (istvt_gemm flags bit 1).  The backward is LinearCatFn's, with respect to x alone: its dy is
+    TemporalAttnFn(diff=2)'s gradient, which is already expressed for projections of the un-differenced rows."""
+
+    @staticmethod
+    def forward(ctx, x, xd, sel_col, *weights):
+        if _overlap['pending']:
+            flush_stale_joins()
+        M = x.shape[0]
+        if (xd.shape != x.shape or xd.stride() != x.stride() or xd.dtype != x.dtype
+                or xd.data_ptr() + M * x.stride(0) * x.element_size() != x.data_ptr()):
+            raise RuntimeError('LinearCatSelFn: xd must be the plane directly in front of x (ops.layernorm_fwd_diff)')
+        w = ops.weight_cat_as(weights, x.dtype)
+        y = ops.linear_fwd(xd, w, pad=True, a_sel_col=sel_col)
+        ctx.save_for_backward(x, *weights)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, *weights = ctx.saved_tensors
+        w = ops.weight_cat_as(weights, dy.dtype)
+        dx = ops.linear_dgrad(dy, w, pad=True) if ctx.needs_input_grad[0] else None
+        grads, n0 = [], 0
+        for i, wi in enumerate(weights):
+            n = wi.shape[0]
+            grads.append(_wgrad(dy[:, n0:n0 + n], x, wi) if ctx.needs_input_grad[3 + i] else None)
+            n0 += n
+        return (dx, None, None, *grads)
+
+
 class FeedForwardFn(Function):
     """Linear -> exact GELU -> Linear (+ residual) (FeedForward, module.py:23-34)."""
 
@@ -379,7 +447,7 @@ class TemporalAttnFn(Function):
         inner = heads * dh
         out = ops.attn_temporal_fwd(qkv[:, :2 * inner], qkv[:, 2 * inner:], B, F, P, heads, dh, diff=diff)
         ctx.save_for_backward(qkv)
-        ctx.geom = (B, F, P, heads, dh, bool(diff))
+        ctx.geom = (B, F, P, heads, dh, int(diff))
         return out
 
     @staticmethod
@@ -655,6 +723,11 @@ class TakeFrameFn(Function):
 
 def layer_norm(x, gamma, beta, eps=1e-5, fork=False, sink=None):
     return LayerNormFn.apply(x, gamma, beta, eps, fork, sink)
+
+
+def layer_norm_diff(x, gamma, beta, eps, geom, fork=False, sink=None):
+    """-> (y, diff[, x]); see LayerNormDiffFn"""
+    return LayerNormDiffFn.apply(x, gamma, beta, eps, geom, fork, sink)
 
 
 def linear(x: Tensor, weight: Tensor, bias=None, residual=None) -> Tensor:

@@ -49,6 +49,15 @@ class PreNorm(nn.Module):
         fork = kwargs.pop('fork', False)
         sink = kwargs.pop('sink', None)
         own_res = isinstance(kwargs.get('residual'), str) and kwargs['residual'] == 'input'
+        geom = self.fn.frame_diff_geometry(x, kwargs.get('hw')) if hasattr(self.fn, 'frame_diff_geometry') else None
+        if geom is not None:
+            # TemporalResidualAttention in bfloat16: the LayerNorm kernel also writes the frame difference (module.py:193),
+            # taken in fp32 before the rounding, and the attention projects q | k from it
+            outs = Fn.layer_norm_diff(x, self.norm.weight, self.norm.bias, self.norm.eps, geom, fork=fork or own_res, sink=sink)
+            if own_res:
+                kwargs['residual'] = outs[2]
+            out = self.fn(outs[0], x_diff=outs[1], **kwargs)
+            return (out, outs[2]) if fork else out
         if fork or own_res:
             y, xr = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, fork=True, sink=sink)
             if own_res:
@@ -133,17 +142,38 @@ class TemporalResidualAttention(nn.Module):
             nn.Dropout(dropout)
         )
 
-    def forward(self, x, hw=None, residual=None, defer_bias=False):
+    def frame_diff_geometry(self, x, hw=None):
+        """(B, F, P) when the enclosing PreNorm should produce the frame difference beside the LayerNorm output
+        (bfloat16 on the MFMA temporal kernels with q | k ending on a GEMM column tile), else None"""
+        hw = self.hw if hw is None else hw
+        inner = self.heads * self.dim_head
+        if x.dtype != torch.bfloat16 or x.dim() != 3 or hw <= 0 or x.shape[1] % hw or (2 * inner) % 256:
+            return None
+        frames = x.shape[1] // hw
+        if frames > 32 or self.dim_head not in (32, 64) or x.shape[0] * x.shape[1] < 256:
+            return None
+        return (x.shape[0], frames, hw)
+
+    def forward(self, x, hw=None, residual=None, defer_bias=False, x_diff=None):
         # module.py:192-206.  The reference differences the LayerNorm output over frames (:193), projects the difference
         # with to_qk and the un-differenced rows with to_v.  to_qk has no bias (:182), so to_qk(x[f] - x[f-1]) =
-        # to_qk(x[f]) - to_qk(x[f-1]): ONE GEMM on the stacked [to_qk | to_v] operand, and the temporal attention kernels
-        # difference q and k in registers (all frames of a position sit in one wavefront) -- no differenced copy of the
-        # activations, one input-gradient GEMM.
+        # to_qk(x[f]) - to_qk(x[f-1]): ONE GEMM on the stacked [to_qk | to_v] operand either way.
+        #   float32: the operand is x and the temporal attention kernels difference q and k in registers (all frames of a
+        #            position sit in one wavefront) -- exact, nothing is rounded in between;
+        #   bfloat16 (x_diff given, from PreNorm): the operand is x_diff for the q | k column tiles and x for the v tiles
+        #            (the GEMM picks the plane per column tile): q', k' are rounded at the magnitude of the DIFFERENCE, as
+        #            in the reference's order.  (Rounds 2-3 differenced bf16 q, k in the kernels: for correlated
+        #            consecutive frames that loses |q| / |q'| in relative precision.)
         b, n, d = x.shape
         hw = self.hw if hw is None else hw
         frames = _frames(n, hw, 'TemporalResidualAttention')
-        qkv = Fn.LinearCatFn.apply(x.reshape(b * n, d), self.to_qk.weight, self.to_v.weight)
-        out = Fn.TemporalAttnFn.apply(qkv, b, frames, hw, self.heads, self.dim_head, True)
+        if x_diff is not None:
+            qkv = Fn.LinearCatSelFn.apply(x.reshape(b * n, d), x_diff.reshape(b * n, d), 2 * self.heads * self.dim_head,
+                                          self.to_qk.weight, self.to_v.weight)
+            out = Fn.TemporalAttnFn.apply(qkv, b, frames, hw, self.heads, self.dim_head, 2)
+        else:
+            qkv = Fn.LinearCatFn.apply(x.reshape(b * n, d), self.to_qk.weight, self.to_v.weight)
+            out = Fn.TemporalAttnFn.apply(qkv, b, frames, hw, self.heads, self.dim_head, 1)
         proj = self.to_out[0]
         plain = self.to_out[1].p == 0.0 or not self.training
         r2 = residual.reshape(b * n, -1) if (residual is not None and plain) else None

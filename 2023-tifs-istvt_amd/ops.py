@@ -319,14 +319,16 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
              C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0,
-             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None, blocked: bool = True):
+             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None, blocked: bool = True, a_sel_col: int = 0):
     """stats: double [R][2][N] accumulator (stem.new_stats): the kernel adds the column sums / sums of squares of the
     stored outputs (fused train-mode BatchNorm statistics); only legal where stats_fusable() says so.
     csum=True (with stats, epi 2 only): only the column sums are accumulated (a bias gradient; the caller folds them
     with istvt_stats_reduce_add).
     blocked (float32 only): blocked summation over the reduction dimension (istvt_gemm flags bit 0).  False = one
     sequential fp32 chain, which the Xception stem's forward / input-gradient convolutions keep (it reproduces the
-    reference CPU run's ReLU / arg-max decisions)."""
+    reference CPU run's ReLU / arg-max decisions).
+    a_sel_col > 0 (istvt_gemm flags bit 1): A is two planes of M rows, the second directly behind the first; output
+    columns at or past a_sel_col (a multiple of 256) take their rows from the second plane."""
     _req(A); _req(B); _req(C)
     if A.dtype != B.dtype:
         raise TypeError('gemm operands must share a dtype (%s vs %s)' % (A.dtype, B.dtype))
@@ -339,7 +341,8 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     rc = _lib.lib().istvt_gemm(A.data_ptr(), lda, int(a_kc), B.data_ptr(), ldb, int(b_kc), C.data_ptr(), ldc, M, N, K,
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
                                stats[0, 0].data_ptr() if stats is not None else None,
-                               stats[0, 1].data_ptr() if (stats is not None and csum is None) else None, int(bool(blocked)),
+                               stats[0, 1].data_ptr() if (stats is not None and csum is None) else None,
+                               int(bool(blocked)) | ((2 | ((a_sel_col // 64) << 16)) if a_sel_col else 0),
                                dtype_code(A), _stream())
     if prof is not None:
         ev1.record()
@@ -362,7 +365,8 @@ def stats_fusable(x: Tensor, w: Tensor) -> bool:
 
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-               gelu: bool = False, pad: bool = False, stats: Optional[Tensor] = None, blocked: bool = True):
+               gelu: bool = False, pad: bool = False, stats: Optional[Tensor] = None, blocked: bool = True,
+               a_sel_col: int = 0):
     """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype); both may
     be row-strided views.  pad=True: the outputs are [M, N] views with line-aligned rows.  stats: see gemm_raw."""
     M, K = x.shape
@@ -380,7 +384,8 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Op
     ldr = 0
     if residual is not None:
         residual, ldr = rows(residual)
-    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr, stats=stats, blocked=blocked)
+    gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, residual=residual, ldr=ldr, stats=stats, blocked=blocked,
+             a_sel_col=a_sel_col)
     return y
 
 
@@ -597,6 +602,26 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, pad: bool 
     return (y if x.dim() == 2 else y.view(*x.shape)), mean, rstd
 
 
+def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: int, F: int, P: int):
+    """LayerNorm of x [B*F*P, D] (rows (b, f, p)) plus the frame difference of module.py:193 taken in fp32 before the
+    rounding to x's dtype.  Returns (y, diff, mean, rstd): y and diff are the two [M, D] planes (line-aligned rows) of
+    ONE buffer, diff first -- the layout gemm_raw(a_sel_col=...) takes."""
+    x2, ldx = rows(_req(x))
+    M, D = x2.shape
+    if M != B * F * P:
+        raise RuntimeError('layernorm_fwd_diff: %d rows are not B=%d x F=%d x P=%d' % (M, B, F, P))
+    ld = pad_ld(D)
+    planes = torch.empty((2, M, ld), dtype=x.dtype, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    with prof('ln_fwd', 3 * M * D * x.element_size()):
+        _lib.check(_lib.lib().istvt_layernorm_fwd_diff(x2.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(),
+                                                       planes[1].data_ptr(), ld, planes[0].data_ptr(), ld, mean.data_ptr(),
+                                                       rstd.data_ptr(), B, F, P, D, eps, dtype_code(x), _stream()),
+                   'istvt_layernorm_fwd_diff')
+    return planes[1][:, :D], planes[0][:, :D], mean, rstd
+
+
 def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
                   dres: Optional[Tensor] = None, pad: bool = False, dcol: Optional[Tensor] = None) -> Tensor:
     """dx of LayerNorm (+ dres, the gradient arriving through the residual fork); dgamma / dbeta (float32 [D]) accumulate;
@@ -665,8 +690,9 @@ def attn_spatial_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, BF: in
 
 def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int, dh: int, diff: bool = False):
     """qk [B*F*P, 2*heads*dh], v [B*F*P, heads*dh] (row-strided views allowed: e.g. the two column ranges of one packed
-    q|k|v projection) -> out [B*F*P, heads*dh] with line-aligned rows.  diff: frame difference on q, k in the kernel
-    (TemporalResidualAttention, module.py:193)."""
+    q|k|v projection) -> out [B*F*P, heads*dh] with line-aligned rows.  diff = 1: frame difference on q, k in the kernel
+    (TemporalResidualAttention, module.py:193); diff = 2 (bfloat16): q, k arrive differenced (layernorm_fwd_diff), the
+    backward still returns gradients w.r.t. the un-differenced projections."""
     inner = heads * dh
     (qk, ldqk), (v, ldv) = rows(_req(qk)), rows(_req(v))
     if F > 17:
@@ -677,7 +703,7 @@ def attn_temporal_fwd(qk: Tensor, v: Tensor, B: int, F: int, P: int, heads: int,
     ldo = out.stride(0)
     with prof('attn_temporal_fwd', 4 * B * F * P * inner * qk.element_size(), 4.0 * B * P * heads * F * F * dh):
         _lib.check(_lib.lib().istvt_attn_temporal_fwd(qk.data_ptr(), ldqk, v.data_ptr(), ldv, out.data_ptr(), ldo, B, F, P,
-                                                      heads, dh, dh ** -0.5, int(bool(diff)), dtype_code(qk), _stream()),
+                                                      heads, dh, dh ** -0.5, int(diff), dtype_code(qk), _stream()),
                    'istvt_attn_temporal_fwd')
     return out
 
@@ -703,7 +729,7 @@ def attn_temporal_bwd(qk: Tensor, v: Tensor, dout: Tensor, B: int, F: int, P: in
     with prof('attn_temporal_bwd', 7 * M * inner * qk.element_size(), 10.0 * B * P * heads * F * F * dh):
         _lib.check(_lib.lib().istvt_attn_temporal_bwd(qk.data_ptr(), ldqk, v.data_ptr(), ldv, dout.data_ptr(), ldo,
                                                       dqk.data_ptr(), dv.data_ptr(), B, F, P, heads, dh, dh ** -0.5,
-                                                      int(bool(diff)), dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
+                                                      int(diff), dtype_code(qk), _stream()), 'istvt_attn_temporal_bwd')
     return (dqkv, None) if packed else (dqk, dv)
 
 

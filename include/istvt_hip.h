@@ -59,7 +59,11 @@ typedef void* istvt_stream_t; /* hipStream_t */
  *           to the running total, so the rounding error grows with 32 + K/32 terms instead of K (the transformer's
  *           Linears and every weight gradient use it: 10x closer to the float64 reference run on golden G5).  0 = one
  *           sequential fp32 FMA chain: the order that reproduces the reference CPU convolutions' ReLU / arg-max
- *           decisions in the Xception stem (forward and input gradient of its convolutions). */
+ *           decisions in the Xception stem (forward and input gradient of its convolutions).
+ *           bit 1 (bfloat16 forward on the persistent NT kernel only, -3 otherwise): A is TWO planes of M rows, the
+ *           second directly behind the first (A + M * lda elements); output columns at or past 64 * (flags >> 16), a
+ *           multiple of 256, take their rows from the second plane.  TemporalResidualAttention (module.py:193-196): q | k
+ *           are projections of the frame-differenced LayerNorm output, v of the plain one -- one 728 -> 1536 GEMM. */
 int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
                int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
                float alpha, double* col_sum, double* col_sumsq, int flags, int dtype, istvt_stream_t stream);
@@ -82,6 +86,11 @@ int istvt_wgrad_group_splits(int count, const int* N, const int* K, int M);
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
 int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,
                         float* rstd, long M, int D, float eps, int dtype, istvt_stream_t stream);
+/* The same plus the frame difference of module.py:193 taken in fp32 before the rounding to the storage type:
+ * diff[(b, f, p)] = y[(b, f, p)] for f < 2, y[(b, f, p)] - y[(b, f - 1, p)] for f >= 2; rows ordered (b, f, p). */
+int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, void* diff,
+                             long ldd, float* mean, float* rstd, int B, int F, int P, int D, float eps, int dtype,
+                             istvt_stream_t stream);
 /* dres (may be NULL) = gradient arriving through the residual connection, added to dx.  dgamma / dbeta accumulate.
  * dcol (may be NULL) accumulates the column sums of dx: the bias gradient of the nn.Linear whose output this LayerNorm
  * normalises (module.py:30,77,186).  ws: float scratch of >= istvt_layernorm_bwd_ws_elems(M, D) elements for the
@@ -118,7 +127,11 @@ int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const void* out, con
  * diff != 0: q and k are the projections of the UN-differenced LayerNorm output; the kernels take the frame
  * difference of module.py:193 on them (q'[f] = q[f] - q[f-1] for f >= 2; exact because to_qk has no bias,
  * module.py:182) and the backward returns gradients with respect to the un-differenced rows.  diff == 0: plain
- * attention over frames (TemporalOnlyAttention, module.py:145-172). */
+ * attention over frames (TemporalOnlyAttention, module.py:145-172).  diff == 2 (bfloat16 only, -3 otherwise): q and k
+ * ARRIVE differenced (projections of istvt_layernorm_fwd_diff's second output: the reference's own order, the rounding
+ * to bfloat16 at the magnitude of the difference); the forward is plain attention, the backward returns dq, dk with
+ * respect to the UN-differenced projections (d q[f] = d q'[f] - d q'[f+1] for f >= 1) so that one input-gradient GEMM
+ * over [dq | dk | dv] follows as with diff == 1. */
 int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v, long ldv, void* out, long ldo, int B, int F, int P,
                             int heads, int dh, float scale, int diff, int dtype, istvt_stream_t stream);
 int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v, long ldv, const void* dout, long ldo, void* dqk,

@@ -252,17 +252,53 @@ def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64, pad=False, diff=False, 
 
     def split(t):                                    # (b f p) (h d) -> b h p f d
         return t.view(B, F, P, heads, dh).permute(0, 3, 2, 1, 4)
-    qk_used = _diff_ref(qkd, B, F, P) if diff else qkd
+    # diff == 2: q, k ARRIVE differenced (plain attention forward); the backward returns the gradient with respect to
+    # the un-differenced projections, i.e. the adjoint of the difference applied to d q', d k'
+    qk_used = _diff_ref(qkd, B, F, P) if diff == 1 else qkd
     q, k = (split(t) for t in qk_used.chunk(2, dim=-1))
     ref = _attn_ref(q, k, split(vd)).permute(0, 3, 2, 1, 4).reshape(M, inner)
     dout = rnd((M, inner), dtype, 3)
     ref.backward(dout.double())
+    if diff == 2:
+        z = torch.zeros_like(qkd, requires_grad=True)
+        (adj,) = torch.autograd.grad(_diff_ref(z, B, F, P), z, qkd.grad)
+        qkd.grad = adj
     dqk, dv = ops.attn_temporal_bwd(qk, v, padded(dout) if pad else dout, B, F, P, heads, dh, diff=diff, packed=packed)
     if packed:
         dqk, dv = dqk[:, :2 * inner], dqk[:, 2 * inner:]
     e = max(relerr(out, ref), relerr(dqk, qkd.grad), relerr(dv, vd.grad))
     # bf16 + diff: the kernel rounds q[f] - q[f-1] to bf16 once more before the MFMA (operand type)
-    return e, TOL[dtype] * (2 if (diff and dtype == torch.bfloat16) else 1)
+    return e, TOL[dtype] * (2 if (diff == 1 and dtype == torch.bfloat16) else 1)
+
+
+def layernorm_diff(dtype, B=3, F=9, P=23, D=728):
+    """LayerNorm + the frame difference of module.py:193 in one kernel (ops.layernorm_fwd_diff): both planes against fp64;
+    the difference plane must carry the precision of the DIFFERENCE -- checked on frames that differ by 2 %"""
+    M = B * F * P
+    base = rnd((B, 1, P, D), torch.float32, 1, 2.0)
+    x = (base + 0.02 * rnd((B, F, P, D), torch.float32, 2)).reshape(M, D).to(dtype)
+    g, b = rnd((D,), torch.float32, 3, 0.2) + 1, rnd((D,), torch.float32, 4, 0.1)
+    y, yd, mean, rstd = ops.layernorm_fwd_diff(x, g, b, 1e-5, B, F, P)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-5)
+    dref = _diff_ref(ref, B, F, P)
+    y0, _, _ = ops.layernorm_fwd(x, g, b, 1e-5, pad=True)
+    planes_ok = yd.data_ptr() + M * yd.stride(0) * yd.element_size() == y.data_ptr()
+    e = max(relerr(y, ref), relerr(yd, dref), 0.0 if torch.equal(y, y0) else 1.0, 0.0 if planes_ok else 1.0)
+    return e, TOL[dtype]
+
+
+def gemm_a_select(M=3000, K=728, N=1536, split=1024):
+    """istvt_gemm flags bit 1: columns < split from plane 0, the rest from plane 1 of a two-plane A (integer-exact)"""
+    dt = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(11)
+    ld = ops.pad_ld(K)
+    planes = torch.full((2, M, ld), float('nan'), dtype=dt, device=DEV)
+    planes[:, :, :K] = torch.randint(-3, 4, (2, M, K), generator=g, device=DEV).to(dt)
+    w = ops.empty_rows(N, K, dt, DEV, True)
+    w.copy_(torch.randint(-2, 3, (N, K), generator=g, device=DEV).to(dt))
+    y = ops.linear_fwd(planes[0][:, :K], w, pad=True, a_sel_col=split)
+    ref = torch.cat((planes[0][:, :K].double() @ w[:split].double().t(), planes[1][:, :K].double() @ w[split:].double().t()), 1)
+    return (0.0 if torch.equal(y.double(), ref.to(dt).double()) else float((y.double() - ref).abs().max())), 0.0
 
 
 # ------------------------------------------------------------------------------------------ misc
@@ -340,6 +376,9 @@ def all_checks():
                         lambda dt=dt, F=F, heads=heads, dh=dh: attn_temporal(dt, 2, F, 37, heads, dh, diff=True, packed=True)))
         for F in (1, 2, 3, 16):                # edge counts: nothing to difference (F <= 2), a full 16-row tile
             out.append(('attn_temporal_diff_F%d_%s' % (F, tag), lambda dt=dt, F=F: attn_temporal(dt, 3, F, 11, 8, 64, diff=True)))
+            if dt == torch.bfloat16:
+                out.append(('attn_temporal_prediff_packed_F%d_%s' % (F, tag),
+                            lambda dt=dt, F=F: attn_temporal(dt, 2, F, 37, 8, 64, diff=2, packed=True)))
         out.append(('tokens_%s' % tag, lambda dt=dt: tokens(dt)))
         out.append(('colsum_cast_%s' % tag, lambda dt=dt: colsum_cast(dt)))
     return out
@@ -933,6 +972,14 @@ def all_checks():  # noqa: F811
     out.append(('attn_spatial_production_BF2304', attn_spatial_production))
     out.append(('attn_spatial_production_P362', lambda: attn_spatial_production(448, 362, 8, 64, 16)))
     out.append(('attn_temporal_production_C2', attn_temporal_production))
+    out.append(('attn_temporal_prediff_padded_F9_bf16', lambda: attn_temporal(torch.bfloat16, 2, 9, 37, 8, 64, pad=True, diff=2, packed=True)))
+    out.append(('attn_temporal_prediff_padded_F17_bf16', lambda: attn_temporal(torch.bfloat16, 2, 17, 19, 8, 64, pad=True, diff=2, packed=True)))
+    out.append(('attn_temporal_prediff_F5_h2_d32_bf16', lambda: attn_temporal(torch.bfloat16, 3, 5, 11, 2, 32, diff=2)))
+    out.append(('layernorm_diff_bf16', lambda: layernorm_diff(torch.bfloat16)))
+    out.append(('layernorm_diff_f32', lambda: layernorm_diff(torch.float32)))
+    out.append(('layernorm_diff_F17_bf16', lambda: layernorm_diff(torch.bfloat16, 2, 17, 197)))
+    out.append(('gemm_a_select', gemm_a_select))
+    out.append(('gemm_a_select_tall', lambda: gemm_a_select(56736, 728, 1536, 1024)))
     out.append(('attn_temporal_production_C4', lambda: attn_temporal_production(16, 17, 197, 8, 64, 128)))
     out.append(('stem_convdense_many_chunks_bf16', conv_dense_many_chunks))
     return out

@@ -181,3 +181,58 @@ def test_wrong_geometry_raises():
         att(torch.zeros(1, 5 * 37, DIM, device='cuda'))
     with pytest.raises(RuntimeError):           # CPU tensors are refused: no fallback path
         M.FeedForward(DIM, 2 * DIM)(torch.zeros(1, 4, DIM))
+
+
+def test_temporal_bf16_correlated_frames_tracks_float32():
+    """consecutive frames of a face video are strongly correlated, so the frame difference of module.py:193
+    cancels most of q and k.  PreNorm(TemporalResidualAttention) in bfloat16 must keep the precision of the DIFFERENCE:
+    the LayerNorm kernel differences in fp32 before rounding and the q | k column tiles of the one GEMM read that plane
+    (round 4).  Checked against the float32 oracle on x[f] = x[f-1] + 0.05 * noise at the model's width, forward and
+    input gradient; the round-3 path (un-differenced operand, bf16 q / k differenced in the kernels: what calling the
+    attention WITHOUT the PreNorm hook still runs) is measured beside it and must be clearly worse on this input."""
+    M, V = _mods()
+    from oracle import istvt_ref as R
+    torch.manual_seed(0)
+    dim, heads, dh, B, F, P = 728, 8, 64, 2, 9, 197
+    pre = M.PreNorm(dim, M.TemporalResidualAttention(dim, heads=heads, dim_head=dh, hw=P))
+    with torch.no_grad():
+        for name, prm in pre.named_parameters():
+            if prm.dim() == 2:
+                # to_qk large enough that the scores of the DIFFERENCED rows are O(1) (a trained model's regime: the
+                # temporal softmax is not uniform); q, k of the un-differenced rows are then ~14x larger
+                prm.copy_(torch.randn_like(prm) * (0.5 if 'to_qk' in name else 0.05))
+    pre = pre.cuda()
+    base = torch.randn(B, 1, P, dim)
+    frames = [base]
+    for _ in range(F - 1):
+        frames.append(frames[-1] + 0.05 * torch.randn(B, 1, P, dim))
+    x32 = torch.cat(frames, 1).reshape(B, F * P, dim)
+    coef = torch.randn(B, F * P, dim)
+
+    p = {'n.weight': pre.norm.weight.detach().cpu(), 'n.bias': pre.norm.bias.detach().cpu()}
+    p.update({'a.' + k: v.detach().cpu() for k, v in pre.fn.state_dict().items()})
+    xr = x32.clone().double().requires_grad_(True)
+    pd = {k: v.double() for k, v in p.items()}
+    ref = R.temporal_residual_attention(pd, 'a', R.layer_norm(pd, 'n', xr), P, heads)
+    (ref * coef.double()).sum().backward()
+
+    def run(hook):
+        x = x32.cuda().bfloat16().requires_grad_(True)
+        if hook:
+            y = pre(x, hw=P)
+        else:       # the round-3 data flow: plain LayerNorm, attention differences bf16 q / k itself
+            from istvt_amd import functional as Fn
+            y = pre.fn(Fn.layer_norm(x, pre.norm.weight, pre.norm.bias, pre.norm.eps), hw=P)
+        (y * coef.cuda().bfloat16()).sum().backward()
+        return relerr(y.float(), ref), relerr(x.grad.float(), xr.grad)
+
+    assert pre.fn.frame_diff_geometry(x32.cuda().bfloat16(), P) == (B, F, P)
+    new_y, new_dx = run(True)
+    old_y, old_dx = run(False)
+    print('correlated frames (5 %%): y err new %.3e old %.3e; dx err new %.3e old %.3e' % (new_y, old_y, new_dx, old_dx))
+    # Measured on MI355X: y 5.2e-3 (round-3 path 7.1e-3), dx 0.22 (0.35).  The output moves little either way -- with
+    # correlated frames the rows of V are nearly equal, so P V hardly depends on P -- but the input gradient does: it goes
+    # through dS = p (dp - delta), where the same correlation makes dp - delta a difference of nearly equal numbers built
+    # from bf16 V (any bfloat16 attention has that floor); the differenced-operand path removes the q / k share of it.
+    assert new_y < 8e-3 and new_y <= old_y * 1.02, (new_y, old_y)
+    assert new_dx < 0.75 * old_dx, (new_dx, old_dx)
