@@ -16,6 +16,7 @@
 // ds_read_b64_tr_b16; f32: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 #define EPI_NONE 0
 #define EPI_GELU_FWD 1   // C = u (pre-activation), C2 = gelu(u)
@@ -302,6 +303,18 @@ static int launch_gemm(const GemmArgs& a, int a_kc, int b_kc, int splitk, hipStr
     return istvt_check_launch();
 }
 
+// CUs the persistent NT kernel leaves alone (istvt_set_cu_reserve): while a collective's kernels hold CUs, a persistent
+// workgroup dealt to one of them would start only when another workgroup has finished its whole tile list and the launch
+// would take up to twice as long; with the grid cut to the CUs that are really free every workgroup is resident at once
+// (666 tiles on 224 workgroups are the same three rounds as on 256).
+static int g_cu_reserve = 0;
+extern "C" int istvt_set_cu_reserve(int n) {
+    if (n < 0 || n > 192) return ISTVT_ERR_SHAPE;
+    const int old = g_cu_reserve;
+    g_cu_reserve = n;
+    return old;
+}
+
 extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc,
                           int M, int N, int K, const float* bias, const void* residual, long ldr, void* C2, int epi,
                           int out_mode, int splitk, float alpha, double* col_sum, double* col_sumsq, int flags, int dtype,
@@ -359,13 +372,14 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                           (long)K * lda * 2 < 0x7fffffffL && (long)K * ldb * 2 < 0x7fffffffL;
         if (q_ok) {
             // persistent NT kernel: one workgroup per CU walks its tiles with the LDS ring kept full across tiles
-            static int cus = 0;
-            if (cus == 0) {
+            static int cus_dev = 0;
+            if (cus_dev == 0) {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess ||
                     hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-                cus = n & ~7;
+                cus_dev = n & ~7;
             }
+            const int cus = std::max(8, (cus_dev - g_cu_reserve) & ~7);      // the CUs this launch may fill (istvt_set_cu_reserve)
             // Balanced rounds: 666 tiles on 256 CUs are three rounds whichever way they are dealt; dealing them to 224
             // workgroups (3 tiles each) takes the same time and leaves 32 CUs free for the whole launch -- for the
             // weight-gradient GEMM running on the side stream -- instead of 102 CUs free for the last round only.
@@ -421,7 +435,10 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             // N=728/K=2912 +2 %, N=512/K=728 +2.5 %, the GELU epilogue GEMMs -5..-8 %, the step +0.5 ms.  Off by
             // default: ISTVT_GEMM_TM=224 forces it (tests/test_model_gpu.py runs the GEMM checks that way), =-1 picks
             // by rounds x height.
-            static const int tm_env = istvt_tune("ISTVT_GEMM_TM", 0);
+            // (read from the environment in EVERY build, unlike the sweep knobs behind -DISTVT_TUNE: it selects another
+            //  kernel instantiation, which tests/test_model_gpu.py::test_gemm_224_row_tile_variant must be able to reach
+            //  in the shipped library, and ops.gemm_kernel_name reads the same variable)
+            static const int tm_env = [] { const char* v = getenv("ISTVT_GEMM_TM"); return v ? atoi(v) : 0; }();
             const int tiles224 = ((M + 223) / 224) * ((N + T256 - 1) / T256);
             const long cost256 = (long)((tiles + cus - 1) / cus) * 256, cost224 = (long)((tiles224 + cus - 1) / cus) * 224;
             if (!col_sum && (tm_env == 224 || (tm_env == -1 && cost224 < cost256))) {

@@ -231,17 +231,24 @@ def flush_stale_joins():
     end-of-backward callback: its join entry and the operands it keeps alive would stay behind, every later backward
     would skip registering a join and the optimizer would read weight gradients the side stream may still be writing.
     Called from the forward (outside any backward every entry is stale) and from _wgrad (an entry of another graph
-    task is stale): launches whatever that pass still had queued, joins the side stream into the CURRENT stream and
-    drops the entry.  The queued weight gradients are LAUNCHED, not dropped: a foreign entry is not always an aborted
-    pass -- a re-entrant backward (torch.utils.checkpoint's recompute, a Function that calls backward) has a task id
-    of its own while the outer pass's gradients are still queued, and those must land.  (For a pass that really
-    aborted the extra launches only add to gradients that are garbage already and are zeroed before the next step.)"""
+    task is stale); joins the side stream into the CURRENT stream and drops the entry.  What happens to the weight
+    gradients that pass still had QUEUED depends on who is asking:
+      * from inside a backward (task != -1) with an entry of ANOTHER task: that entry need not be an aborted pass -- a
+        re-entrant backward (torch.utils.checkpoint's recompute, a Function that calls backward) has a task id of its
+        own while the outer pass's gradients are still queued, and those must land: they are LAUNCHED;
+      * from a forward (task == -1): a pending entry can only be left by a backward that aborted.  The usual loop is
+        zero_grad() -> forward -> backward (and the fused optimizer zeroes inside step()), so the gradients have been
+        zeroed since: launching the aborted pass's dy^T x products now would add them into the NEXT step's gradients
+        (an OOM-skip-batch loop would silently train on a batch it meant to skip).  They are DROPPED."""
     if not _overlap['pending']:
         return
     task = _graph_task()
     for dev in list(_overlap['pending']):
         if task == -1 or _overlap['pending'][dev][1] != task:
-            _flush_group(dev)
+            if task == -1:
+                _overlap['queue'].pop(dev, None)
+            else:
+                _flush_group(dev)
             side = _overlap['streams'].get(dev)
             if side is not None:
                 torch.cuda.current_stream(torch.device('cuda', dev)).wait_stream(side)

@@ -352,6 +352,15 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     _lib.check(rc, 'istvt_gemm')
 
 
+def set_cu_reserve(n: int) -> int:
+    """CUs the persistent NT GEMM launches issued from now on leave free (istvt_set_cu_reserve); returns the previous
+    value.  parallel.GradBucket raises it while its asynchronous all-reduce is in flight."""
+    rc = _lib.lib().istvt_set_cu_reserve(int(n))
+    if rc < 0:
+        _lib.check(rc, 'istvt_set_cu_reserve')
+    return rc
+
+
 def stats_fusable(x: Tensor, w: Tensor) -> bool:
     """whether linear_fwd(x, w, stats=...) may be used: the problem runs on the persistent bf16 NT kernel (the only one
     whose epilogue accumulates column statistics)"""

@@ -68,6 +68,10 @@ class GradBucket:
         self.grad_scale = 1.0           # what the next fused optimizer step multiplies the gradients by (1 / world size)
         self._early = None
         self._early_work = None
+        # CUs left to the collective's kernels while the early all-reduce overlaps the stem backward (RCCL runs one
+        # workgroup per channel; the persistent GEMM kernels need whole CUs).  ISTVT_RCCL_CU_RESERVE overrides.
+        self.cu_reserve = int(os.environ.get('ISTVT_RCCL_CU_RESERVE', '32'))
+        self._reserved = False
         self._on_ready = None
         self.flat_params = None
         if flatten_params:
@@ -123,6 +127,12 @@ class GradBucket:
             if device.type == 'cuda':
                 Fn.join_side_stream(device.index)       # the side-stream weight gradients are part of the slice
             me._early_work = (dist.all_reduce(me.flat[lo:me.numel], op=dist.ReduceOp.SUM, group=group, async_op=True), lo)
+            # the collective's kernels hold CUs until it is done: the persistent GEMMs of the stem backward, which runs
+            # beside it, are launched on the CUs that are left (ops.set_cu_reserve), reset in all_reduce()
+            if device.type == 'cuda' and me.cu_reserve > 0:
+                from . import ops
+                ops.set_cu_reserve(me.cu_reserve)
+                me._reserved = True
 
         self._on_ready = on_ready
         Fn.grad_ready_hooks.append(on_ready)
@@ -168,6 +178,10 @@ class GradBucket:
         if self._early_work is not None:    # the transformer's slice is already in flight (enable_early_all_reduce)
             work, lo = self._early_work     # (lo travels with the work: disable_early_all_reduce() may have run since)
             self._early_work = None
+            if self._reserved:
+                from . import ops
+                ops.set_cu_reserve(0)           # what is launched from here on runs after the collective (work.wait())
+                self._reserved = False
             if lo > 0:
                 dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM, group=group)
             work.wait()
@@ -272,7 +286,9 @@ class _FusedOptimizer(torch.optim.Optimizer):
         groups = sd['param_groups']
         if len(groups) != 1 or len(groups[0]['params']) != len(self.bucket.params):
             raise ValueError('fused optimizer: expected ONE param group over %d parameters' % len(self.bucket.params))
-        self.hyper.update({k: v for k, v in groups[0].items() if k != 'params' and k in self.hyper})
+        # every saved key, as torch.optim does (a checkpoint written with an LR scheduler attached carries
+        # 'initial_lr', which CosineAnnealingLR(last_epoch=E) needs on resume); the kernels read only the keys they know
+        self.hyper.update({k: v for k, v in groups[0].items() if k != 'params'})
         state = sd['state']
         steps = 0
         for i, p, off, n in self._slices():

@@ -79,6 +79,22 @@ def parse():
                          'time gather).  On a one-GPU box this is the only way to drive RCCL itself through the calls, streams '
                          'and waits of the data-parallel step; values are unchanged and the timing says what the calls cost '
                          'without any link')
+    # ---- the reference's own flag names (train_CNN.py:1016-1057), for the options that concern this path ----
+    ap.add_argument('--model_name', '-mn', default='resnet_3d',
+                    help="train_CNN.py -mn: 'resnet_3d' is the ISTVT model (models.py:240-282); the only one this benchmark times")
+    ap.add_argument('--batch_size', '-bz', type=int, default=None,
+                    help='train_CNN.py -bz: the GLOBAL batch over the -d devices (per-GPU batch = bz // devices, train_CNN.py:180-181)')
+    ap.add_argument('--sequence_length', '-sl', type=int, default=None, help='train_CNN.py -sl: frames per clip (= --frames)')
+    ap.add_argument('--input_size', '-is', type=int, default=None, help='train_CNN.py -is: input side (= --size)')
+    ap.add_argument('--optimizer', '-opt', default='SGD', choices=['SGD', 'Adam'],
+                    help='train_CNN.py -opt: SGD(momentum 0.9) or Adam (= AdamW(betas 0.9/0.999, eps 1e-8), train_CNN.py:198-201)')
+    ap.add_argument('--learning_rate', '-lr', type=float, default=0.001)
+    ap.add_argument('--weight_decay', '-wd', type=float, default=0.0)
+    ap.add_argument('--run_device', '-d', default=None,
+                    help='train_CNN.py -d "0,1,...": that many devices.  The reference wraps the model in nn.DataParallel '
+                         '(train_CNN.py:185-186); here it means one process per device (= --gpus N)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short C4 / C5 / C1 legs that fill the other_configs field of the default run')
     ap.add_argument('--plumbing-only', action='store_true',
                     help='exercise only the launch / process-group / timing / JSON plumbing (no model, no GPU needed): '
                          'what the CPU test of the self-launching --gpus N path runs')
@@ -87,6 +103,30 @@ def parse():
               'C4': dict(frames=16), 'C5': dict(batch=64, attn_fp8=True)}.get(a.config, {})
     for k, v in preset.items():
         setattr(a, k, v)
+    apply_reference_flags(a)
+    return a
+
+
+def apply_reference_flags(a):
+    """train_CNN.py's names onto this script's: -d "0,1" -> --gpus 2 (num_device = (len(device_no) + 1) // 2, :179),
+    -bz B -> per-GPU batch B // devices (:181), -sl -> --frames, -is -> --size.  Anything but the ISTVT model is refused."""
+    if a.model_name != 'resnet_3d':
+        raise SystemExit("bench.py times the ISTVT hot path only: -mn resnet_3d (got %r; 'xception' etc. are constructible "
+                         "through istvt_amd.network.models.model_selection but are not this benchmark)" % a.model_name)
+    if a.run_device is not None:
+        ndev = (len(a.run_device) + 1) // 2
+        if a.gpus == 1:
+            a.gpus = ndev
+        elif a.gpus != ndev:
+            raise SystemExit('bench.py: --gpus %d contradicts -d %s (%d devices)' % (a.gpus, a.run_device, ndev))
+    if a.batch_size is not None:
+        if a.batch_size % a.gpus:
+            raise SystemExit('bench.py: -bz %d is not divisible by the %d devices' % (a.batch_size, a.gpus))
+        a.batch = a.batch_size // a.gpus
+    if a.sequence_length is not None:
+        a.frames = a.sequence_length
+    if a.input_size is not None:
+        a.size = a.input_size
     return a
 
 
@@ -110,10 +150,28 @@ def self_launch(a):
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
     env['MASTER_ADDR'] = '127.0.0.1'
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    env.setdefault('ISTVT_PIN_RANKS', '1')      # each rank binds itself to its own share of the cores (pin_rank below)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     return subprocess.call(cmd, env=env)
+
+
+def pin_rank(local_rank, world):
+    """Bind this rank's Python (the thread that enqueues ~1400 launches per step) to its own contiguous share of the cores
+    the job may use: eight ranks left to the scheduler migrate and share cores.  Returns the core list (or None)."""
+    if world <= 1 or os.environ.get('ISTVT_PIN_RANKS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
 
 
 def plumbing_only(a, world, rank):
@@ -167,10 +225,111 @@ def cpu_baseline(frames, size, depth, clips=2, reps=3):
         if rep > 0:
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+    # "C1 exactly as stated": 1 clip, T=4, 96x96, 2-layer ISTVT, forward only (BASELINE.json configs[0])
+    g1 = R.stem_out_side(96)
+    sh1 = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
+    sh1.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(4, g1, depth=2).items()})
+    p1 = R.random_params(sh1, seed=0)
+    x1 = torch.randn((1, 4, 3, 96, 96), generator=torch.Generator().manual_seed(0))
+    t1 = []
+    with torch.no_grad():
+        for rep in range(6):
+            t0 = time.perf_counter()
+            R.xception_vidtr_forward(p1, x1, depth=2)
+            if rep > 0:
+                t1.append(time.perf_counter() - t0)
+    d1 = sorted(t1)[len(t1) // 2]
+    c1 = {'value': round(1.0 / d1, 3), 'unit': 'clips/s', 'ms': round(d1 * 1e3, 1),
+          'sample': 'C1: 1 clip, T=4, 96x96, depth 2, forward, fp32, train-mode BatchNorm; 1 warm-up + 5 repetitions, median'}
+    return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port', 'c1_forward': c1,
             'sample': 'batch of %d clips (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads: 1 warm-up + '
                       '%d repetitions, median %.1f s (all: %s)' % (clips, frames, size, size, depth, torch.get_num_threads(), reps,
                                                                  dt, ', '.join('%.1f' % t for t in times))}
+
+
+def other_configs(a, local_rank, steps=10, warmup=5):
+    """BASELINE.json configs the driver's one default run would otherwise never see: C4 (B=32, T=16: the long-clip
+    temporal-attention stress), C5 (B=64, fp8 e4m3 operands in the spatial-attention MFMAs; the logit delta against bf16
+    on identical weights and inputs) and C1 (1 clip, T=4, 96x96, depth 2, float32 forward: the reference's own
+    CPU-runnable case, here on the GPU).  Each: fresh model (seed 0), `warmup` + `steps` full training steps with the
+    fused SGD (C1: forwards), inputs resident in HBM.  Never the headline value."""
+    import gc
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import ops, parallel
+    from istvt_amd import stem as stem_mod
+    from istvt_amd.network.vivit.vivit import XceptionVidTr
+    dev = torch.device('cuda', local_rank)
+    res = {}
+
+    def free():
+        ops.invalidate_weight_cache()
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def leg(name, batch, frames, size, depth, dtype, fp8, forward_only):
+        free()
+        t_build = time.perf_counter()
+        torch.manual_seed(0)
+        model = XceptionVidTr(num_frames=frames, grid=stem_mod.out_side(size), depth=depth, compute_dtype=dtype,
+                              attn_fp8=fp8).to(dev).train()
+        g = torch.Generator(device='cpu').manual_seed(1)
+        x = torch.randn((batch, frames, 3, size, size), generator=g).to(dev)
+        labels = (torch.rand((batch,), generator=g) > 0.5).float().to(dev)
+        rec = {'workload': '%s: B=%d T=%d %dx%d depth %d %s%s' % (name, batch, frames, size, size, depth,
+                                                                   'bf16' if dtype == torch.bfloat16 else 'f32',
+                                                                   ' + fp8 spatial-attention operands' if fp8 else '')}
+        if fp8:
+            # the same weights and inputs with and without the fp8 operands (train-mode forward, before any update)
+            with torch.no_grad():
+                l8 = model(x).float().view(-1)
+                for m in model.modules():
+                    if hasattr(m, 'attn_fp8'):
+                        m.attn_fp8 = False
+                l16 = model(x).float().view(-1)
+                for m in model.modules():
+                    if hasattr(m, 'attn_fp8'):
+                        m.attn_fp8 = True
+            rec['fp8_vs_bf16_logits'] = {'max_abs_delta': round(float((l8 - l16).abs().max()), 6),
+                                         'max_abs_logit': round(float(l16.abs().max()), 4)}
+        if forward_only:
+            def step():                 # train-mode forward (BatchNorm batch statistics), as the CPU leg of cpu_baseline runs it
+                with torch.no_grad():
+                    return model(x).sum()
+        else:
+            live = [p for _, p in parallel.live_named_parameters(model)]
+            bucket = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=True)
+            opt = parallel.FusedSGD(bucket, lr=1e-3, momentum=0.9, weight_decay=0, zero_grad=True)
+            crit = torch.nn.BCEWithLogitsLoss()
+
+            def step():
+                opt.zero_grad()
+                loss = crit(model(x).view(-1), labels)
+                loss.backward()
+                opt.step()
+                return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        rec.update({'ms_per_step': round(dt * 1e3, 3), 'clips_per_s': round(batch / dt, 2), 'steps': steps, 'warmup': warmup,
+                    'what': 'train-mode forward, no_grad' if forward_only else 'train step (fwd+bwd+fused SGD)',
+                    'loss' if not forward_only else 'logit_sum': round(float(last.item()), 5),
+                    'wall_s_incl_build': round(time.perf_counter() - t_build, 1)})
+        gf = GF_PER_CLIP_FWD_BWD.get(frames) if (size == 224 and depth == 12 and not forward_only) else None
+        if gf:
+            rec['model_tflops'] = round(batch / dt * gf / 1e3, 1)
+        res[name] = rec
+
+    leg('C4', 32, 16, 224, 12, torch.bfloat16, False, False)
+    leg('C5', 64, 8, 224, 12, torch.bfloat16, True, False)
+    leg('C1', 1, 4, 96, 2, torch.float32, False, True)
+    free()
+    return res
 
 
 def config_name(a, world):
@@ -196,41 +355,20 @@ def pmc_summary_path():
     return os.path.join(d, names[-1]) if names else None
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        raise SystemExit(self_launch(a))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if a.plumbing_only:
-        return plumbing_only(a, world, rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if os.environ.get('ISTVT_BENCH_REHEARSAL'):
-            # functional rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo instead of RCCL
-            # (the timing of such a run means nothing)
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            torch.cuda.set_device(local_rank)
-            # device_id: the communicator is created now, on this rank's GPU, and barrier() knows its device
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(0)
-        if a.rccl_rehearsal:
-            import socket
-            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-                s.bind(('127.0.0.1', 0))
-                port = s.getsockname()[1]
-            os.environ['ISTVT_FORCE_COLLECTIVES'] = '1'
-            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
-                                    device_id=torch.device('cuda', 0))
-    # `multi`: the collectives of the data-parallel step run (N > 1, or the one-rank RCCL rehearsal)
-    multi = world > 1 or a.rccl_rehearsal
+def make_optimizer(a, parallel, bucket, live):
+    """train_CNN.py:198-201: SGD(lr, momentum 0.9, weight_decay) or AdamW(lr, betas (0.9, 0.999), eps 1e-8, weight_decay)"""
+    if a.torch_optimizer:
+        if a.optimizer == 'Adam':
+            return torch.optim.AdamW(live, lr=a.learning_rate, betas=(0.9, 0.999), eps=1e-8, weight_decay=a.weight_decay)
+        return torch.optim.SGD(live, lr=a.learning_rate, momentum=0.9, weight_decay=a.weight_decay)
+    if a.optimizer == 'Adam':
+        return parallel.FusedAdamW(bucket, lr=a.learning_rate, betas=(0.9, 0.999), eps=1e-8, weight_decay=a.weight_decay,
+                                   zero_grad=True)
+    return parallel.FusedSGD(bucket, lr=a.learning_rate, momentum=0.9, weight_decay=a.weight_decay, zero_grad=True)
+
+
+def headline(a, world, rank, local_rank, multi):
+    """the timed run of the configuration `a` names; returns the JSON dict on rank 0 (None elsewhere)"""
     dev = torch.device('cuda', local_rank)
 
     import istvt_pkg
@@ -249,10 +387,7 @@ def main():
     live_named = parallel.live_named_parameters(model)
     live = [p for _, p in live_named]
     bucket = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=not a.torch_optimizer)
-    if a.torch_optimizer:
-        opt = torch.optim.SGD(live, lr=1e-3, momentum=0.9, weight_decay=0)     # train_CNN.py:200
-    else:                                   # the same update in one launch over the flat buffers, zero-grad included
-        opt = parallel.FusedSGD(bucket, lr=1e-3, momentum=0.9, weight_decay=0, zero_grad=True)
+    opt = make_optimizer(a, parallel, bucket, live)      # fused: the update in one launch over the flat buffers, zero-grad included
     crit = torch.nn.BCEWithLogitsLoss()                                      # train_CNN.py:148
     if multi and not a.no_early_allreduce:
         # the transformer's 98.8 % of the bucket is all-reduced while the stem backward still runs (parallel.py)
@@ -316,6 +451,38 @@ def main():
         per_rank = [round(float(t.item()) / a.steps * 1e3, 3) for t in allt]
         elapsed = max(float(t.item()) for t in allt)
     loss_val = float(loss.item())
+
+    # ---- N > 1: the same K steps under the OTHER collective schedule, so that one run decides between them: the default
+    # starts the transformer's 98.8 % of the bucket from inside backward (two collectives per step: that slice, then the
+    # stem's 4.4 MB), the alternative is north_star's single blocking all-reduce after backward.
+    schedules = None
+    if multi and not a.eval:
+        def timed(k):
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sync()
+            mine_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            all_ = [torch.zeros_like(mine_) for _ in range(world)]
+            dist.all_gather(all_, mine_)
+            return [float(t.item()) for t in all_]
+        first = 'single_blocking_allreduce' if a.no_early_allreduce else 'early_two_piece_allreduce'
+        schedules = {first: {'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'per_rank_ms_per_step': per_rank, 'headline': True}}
+        if a.no_early_allreduce:
+            bucket.enable_early_all_reduce(next(i for i, (n, _) in enumerate(live_named) if n.startswith('vit.')))
+            other = 'early_two_piece_allreduce'
+        else:
+            bucket.disable_early_all_reduce()
+            other = 'single_blocking_allreduce'
+        step(); step()
+        ts = timed(a.steps)
+        schedules[other] = {'ms_per_step': round(max(ts) / a.steps * 1e3, 3),
+                            'per_rank_ms_per_step': [round(t / a.steps * 1e3, 3) for t in ts], 'headline': False}
+        if a.no_early_allreduce:
+            bucket.disable_early_all_reduce()
+        else:
+            bucket.enable_early_all_reduce(next(i for i, (n, _) in enumerate(live_named) if n.startswith('vit.')))
 
     # ---- extra field: the same K steps with the opt-in dead-row elimination (identical logits / gradients, fewer FLOPs)
     dre = None
@@ -490,6 +657,12 @@ def main():
         # the host 35 ms per replay on this ROCm, no better than the eager loop.)
         out['host_enqueue_ms_per_step'] = round(t_enq * 1e3, 3)
         out['config']['dead_row_elimination'] = bool(a.dead_row_elimination)
+        # DSTTr reads one row per clip of the final LayerNorm (vivit.py:144-146): only those rows are normalised
+        # (bit-identical, < 0.1 % of the step), unlike dead_row_elimination this is always on
+        out['config']['final_norm_class_rows_only'] = True
+        out['config']['optimizer'] = ('AdamW' if a.optimizer == 'Adam' else 'SGD(momentum 0.9)') + (' torch' if a.torch_optimizer else ' fused')
+        out['config']['lr'] = a.learning_rate
+        out['config']['weight_decay'] = a.weight_decay
         if dre:
             out['with_dead_row_elimination'] = dre
         if hostb:
@@ -499,7 +672,10 @@ def main():
                                   'per_rank_ms_per_step': per_rank,
                                   'grad_bucket_MB': round(bucket.numel * 4 / 2**20, 1),
                                   'scale_folded_into_optimizer': bool(bucket.defer_scale),
-                                  'rccl_rehearsal': bool(a.rccl_rehearsal)}
+                                  'rccl_rehearsal': bool(a.rccl_rehearsal),
+                                  'collectives_per_step': 1 if a.no_early_allreduce else 2,
+                                  'cu_reserve_during_early_allreduce': bucket.cu_reserve,
+                                  'schedules': schedules}
         ms = torch.cuda.memory_stats(dev)
         out['allocator'] = {'reserved_GB': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),
                             'device_allocs': ms.get('num_device_alloc', 0), 'device_frees': ms.get('num_device_free', 0),
@@ -508,6 +684,54 @@ def main():
             out['roofline'] = roof
         if kern:
             out['kernels'] = kern
+        return out
+    return None
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(a))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.plumbing_only:
+        return plumbing_only(a, world, rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if os.environ.get('ISTVT_BENCH_REHEARSAL'):
+            # functional rehearsal of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo instead of RCCL
+            # (the timing of such a run means nothing)
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            # device_id: the communicator is created now, on this rank's GPU, and barrier() knows its device
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+        if a.rccl_rehearsal:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+                s.bind(('127.0.0.1', 0))
+                port = s.getsockname()[1]
+            os.environ['ISTVT_FORCE_COLLECTIVES'] = '1'
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                    device_id=torch.device('cuda', 0))
+    # `multi`: the collectives of the data-parallel step run (N > 1, or the one-rank RCCL rehearsal)
+    multi = world > 1 or a.rccl_rehearsal
+    pinned = pin_rank(local_rank, world)
+    out = headline(a, world, rank, local_rank, multi)
+    if rank == 0:
+        if pinned is not None and 'distributed' in out:
+            out['distributed']['cores_per_rank'] = len(pinned)
+        default_c2 = (a.batch, a.frames, a.size, a.depth, a.dtype, bool(a.attn_fp8)) == (32, 8, 224, 12, 'bf16', False)
+        if world == 1 and default_c2 and not (a.eval or a.no_other_configs or a.rccl_rehearsal):
+            # BASELINE.json's other single-GPU configurations, short legs after the headline (its model is freed)
+            out['other_configs'] = other_configs(a, local_rank)
         if world == 1 and not a.no_cpu_baseline and not a.eval:
             out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
         print(json.dumps(out), flush=True)

@@ -82,6 +82,11 @@ int istvt_wgrad_group(int count, const void* const* dy, const long* lddy, const 
                       float* const* out, const int* N, const int* K, int M, int splits, float* ws, long ws_elems,
                       istvt_stream_t stream);
 int istvt_wgrad_group_splits(int count, const int* N, const int* K, int M);
+/* CUs the persistent NT GEMM launches that follow leave free (0 = none, the default; returns the previous value): set
+ * while a collective's kernels occupy CUs (the data-parallel gradient all-reduce that overlaps the stem backward,
+ * train_CNN.py:185-186 -> parallel.GradBucket), so that every persistent workgroup is resident at once instead of
+ * queueing behind a whole tile list.  Host-side state of the calling process, read at launch. */
+int istvt_set_cu_reserve(int n);
 
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
 int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,

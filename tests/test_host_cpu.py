@@ -360,3 +360,52 @@ def test_dualnet_xception_surface(pkg, golden_dir):
     assert 'last_linear.weight' in m.state_dict() and 'fc.weight' not in m.state_dict()
     with pytest.raises(RuntimeError, match='ROCm device'):
         net.fea_5_8(torch.zeros(1, 728, 5, 5))
+
+
+def test_stale_weight_gradient_queue_is_dropped_by_a_forward_and_launched_inside_a_backward(pkg, monkeypatch):
+    """a backward that aborted leaves its join entry and its QUEUED weight-gradient group behind.  Found by
+    the next forward (no graph task is running) the queue must be dropped -- the gradients have been zeroed since, launching
+    the old dy^T x products would corrupt the next step; found from inside another backward (a re-entrant pass) it must be
+    launched."""
+    from istvt_amd import functional as Fn, ops
+    launched = []
+    monkeypatch.setattr(ops, 'linear_wgrad_group', lambda q: launched.append(list(q)))
+    monkeypatch.setitem(Fn._overlap, 'on', False)
+    try:
+        Fn._overlap['pending'][0] = (None, 12345)            # (main stream, task id) of a pass that never ran its callback
+        Fn._overlap['queue'][0] = ['stale-entry']
+        Fn._overlap['keep'][0] = ['operands']
+        Fn.flush_stale_joins()                               # called from a forward: torch reports task id -1
+        assert launched == [] and 0 not in Fn._overlap['pending'] and 0 not in Fn._overlap['queue'] and 0 not in Fn._overlap['keep']
+        Fn._overlap['pending'][0] = (None, 12345)
+        Fn._overlap['queue'][0] = ['outer-pass-entry']
+        monkeypatch.setattr(Fn, '_graph_task', lambda: 777)  # inside a backward with another task id
+        Fn.flush_stale_joins()
+        assert launched == [['outer-pass-entry']] and 0 not in Fn._overlap['pending']
+    finally:
+        for k in ('pending', 'queue', 'keep'):
+            Fn._overlap[k].pop(0, None)
+
+
+def test_bench_accepts_the_reference_training_flags(monkeypatch):
+    """SURVEY section 5 / VERDICT r3 row g: the names a train_CNN.py user types (train_CNN.py:1016-1057) on the build's
+    entry point -- -mn resnet_3d -sl T -is S -bz B -opt SGD|Adam -lr -wd -d "0,1,.." -- mapped as the reference computes
+    them (num_device = (len(device_no) + 1) // 2, per-device batch = batch_size // num_device, :179-181)."""
+    import importlib
+    bench = importlib.import_module('bench')
+
+    def parse(*argv):
+        monkeypatch.setattr(sys, 'argv', ['bench.py'] + list(argv))
+        return bench.parse()
+    a = parse('-mn', 'resnet_3d', '-sl', '6', '-is', '300', '-bz', '16', '-opt', 'Adam', '-lr', '0.0005', '-wd', '0.01', '-d', '0,1')
+    assert (a.frames, a.size, a.batch, a.gpus, a.optimizer, a.learning_rate, a.weight_decay) == (6, 300, 8, 2, 'Adam', 0.0005, 0.01)
+    a = parse('-d', '0,1,2,3,4,5,6,7', '-bz', '256')
+    assert (a.gpus, a.batch) == (8, 32)                     # C3: 8 x 32 clips
+    a = parse()
+    assert (a.gpus, a.batch, a.frames, a.size, a.optimizer, a.learning_rate) == (1, 32, 8, 224, 'SGD', 0.001)
+    with pytest.raises(SystemExit):
+        parse('-mn', 'xception')
+    with pytest.raises(SystemExit):
+        parse('-bz', '15', '-d', '0,1')
+    with pytest.raises(SystemExit):
+        parse('--gpus', '4', '-d', '0,1')

@@ -774,6 +774,12 @@ def test_bench_two_rank_path_rehearsal():
     assert out['distributed']['ranks'] == 2 and len(out['distributed']['per_rank_ms_per_step']) == 2
     assert out['value'] > 0 and abs(out['value'] - 2 * 2 * 1e3 / out['ms_per_step']) < 1e-2 * out['value']
     assert 'roofline' in out and out['vs_baseline'] is None
+    # ONE run times both collective schedules and names the headline one
+    sch = out['distributed']['schedules']
+    assert set(sch) == {'early_two_piece_allreduce', 'single_blocking_allreduce'}
+    assert sch['early_two_piece_allreduce']['headline'] and not sch['single_blocking_allreduce']['headline']
+    assert all(len(v['per_rank_ms_per_step']) == 2 and v['ms_per_step'] > 0 for v in sch.values())
+    assert out['distributed']['collectives_per_step'] == 2 and out['config']['final_norm_class_rows_only'] is True
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
