@@ -30,6 +30,20 @@
 #ifndef ISTVT_T_ORDER
 #define ISTVT_T_ORDER 0
 #endif
+// ISTVT_T_SCHED: 0 = the schedule of rounds 2-3 (every fragment read in the load slots, ring of ten units).  1 = round 4:
+// the schedule of gemm256q.h's ISTVT_Q_SCHED 1 -- a load slot of this kernel carried 32 transposing fragment reads besides
+// its four DMA pieces (twice the LDS instructions of the NT kernel's), against 32 MFMAs in the other group's slot:
+//      L_A(k)   DMA AL(k+1), AH(k+1)    reads B(k) (8 fragments)            wait: AH(k) landed       vmcnt(8)
+//      C_A(k)   32 MFMA AL(k) x B(k), the 8 fragments of AL(k) read between them
+//      L_B(k)   DMA BL(k+2), BH(k+2)    reads AH(k) (8 fragments)           wait: B(k+1) landed      vmcnt(8)
+//      C_B(k)   32 MFMA AH(k) x B(k)                                        wait: AL(k+1) landed     vmcnt(6)
+// unit X(k) in ring slot 4 (k & 1) + {AL 0, BL 1, BH 2, AH 3} (eight units; the epilogue slabs are separate again); WAR / RAW
+// / vmcnt reasoning as in gemm256q.h.  K tiles past the split's end are requested like any other: their rows are out of
+// range for the descriptors, so they cost no traffic, write zeros into slots nobody reads and keep the vmcnt counts
+// constant; the kernel drains them before its epilogue.
+#ifndef ISTVT_T_SCHED
+#define ISTVT_T_SCHED 1
+#endif
 
 __device__ __forceinline__ int tswz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
@@ -70,7 +84,7 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
     // the K loop never touches: one tile per workgroup) aliases the ring and the ring gets a fifth slot: the producer
     // runs 8..11 units ahead of the consumer instead of 6..9.  Five is not a power of two: slot indices are counters
     // that wrap, the two pair bases of a K tile are scalars.
-    constexpr bool R10 = ISTVT_T_RING10 != 0;
+    constexpr bool R10 = ISTVT_T_RING10 != 0 && ISTVT_T_SCHED == 0;
     constexpr int TNP = R10 ? 5 : 4;
     __shared__ __attribute__((aligned(16))) char smem[TNP * 2 * QU_BYTES + (R10 ? 0 : 8 * PSLAB_BYTES)];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,6 +120,97 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
     }
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.A), 0, k_end * lda * 2, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.B), 0, k_end * ldb * 2, RSRC_FLAGS);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if ISTVT_T_SCHED == 1
+    {
+        const unsigned ring0 = (unsigned)(__SIZE_TYPE__)(lds_void*)smem + wave * 1024;
+        int ka = 0, kb = 0;                                // the K tiles whose A / B units go out next
+        auto issue_a = [&](const int hi) {                 // AL (hi = 0) / AH (hi = 1) of K tile ka: two pieces
+            if (ISTVT_T_DIAG & 4) return;
+            const int sa = (k_begin + ka * 64) * lda * 2 + (bm0 + (hi ? 128 : 0)) * 2;
+            const unsigned dst = ring0 + ((ka & 1) * 4 + (hi ? 3 : 0)) * QU_BYTES;
+            dma16_lds(a_rs, dst, va[0], sa);
+            dma16_lds(a_rs, dst + 8192, va[1], sa);
+        };
+        auto issue_b = [&](const int hi) {                 // BL / BH of K tile kb
+            if (ISTVT_T_DIAG & 4) return;
+            const int sb = (k_begin + kb * 64) * ldb * 2 + (bn0 + (hi ? 128 : 0)) * 2;
+            const unsigned dst = ring0 + ((kb & 1) * 4 + 1 + hi) * QU_BYTES;
+            dma16_lds(b_rs, dst, vb[0], sb);
+            dma16_lds(b_rs, dst + 8192, vb[1], sb);
+        };
+        issue_b(0); issue_b(1); ++kb;                      // B(0)
+        issue_a(0); issue_a(1); ++ka;                      // AL(0), AH(0)
+        issue_b(0); issue_b(1); ++kb;                      // B(1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // B(0), AL(0) landed (own pieces)
+        slot_barrier();
+        if (wm == 1) slot_barrier();                       // stagger: waves 4..7 run one slot behind
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* ubase = smem + (kt & 1) * 4 * QU_BYTES;
+            const char* ua_lo = ubase;
+            const char* ua_hi = ubase + 3 * QU_BYTES;
+            const char* ub = ubase + (1 + (wn >> 1)) * QU_BYTES;
+            bf16x8 af[4][2], bq[4][2];
+            auto mma4 = [&](const int mt, const int t, const int kh) {
+                if (ISTVT_T_DIAG & 1) return;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[nt][kh], af[t][kh], acc[mt][nt], 0, 0, 0);
+            };
+            auto fa = [&](const char* base, const int t, const int kh) -> bf16x8 {
+                return (ISTVT_T_DIAG & 2) ? diag_frag(lane + t + kh) : t_frag(base, kh * 32 + 8 * g, wm * 64 + t * 16, r);
+            };
+            // ---- L_A
+            issue_a(0); issue_a(1); ++ka;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+                    bq[t][kh] = (ISTVT_T_DIAG & 2) ? diag_frag(lane - t - kh) : t_frag(ub, kh * 32 + 8 * g, (wn & 1) * 64 + t * 16, r);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // AH(k) landed
+            slot_barrier();
+            // ---- C_A: the A fragments (i: t = i & 3, kh = i >> 2) two ahead of the MFMAs that use them
+            af[0][0] = fa(ua_lo, 0, 0);
+            af[1][0] = fa(ua_lo, 1, 0);
+#define TSTEP(i)                                                                             \
+            if ((i) + 2 < 8) af[((i) + 2) & 3][((i) + 2) >> 2] = fa(ua_lo, ((i) + 2) & 3, ((i) + 2) >> 2); \
+            mma4((i) & 3, (i) & 3, (i) >> 2);
+            TSTEP(0) TSTEP(1) TSTEP(2) TSTEP(3) TSTEP(4) TSTEP(5) TSTEP(6) TSTEP(7)
+#undef TSTEP
+            if (!(ISTVT_T_DIAG & 3)) {
+                // a fragment is two ds_read_b64_tr_b16: 6 reads, then 4 MFMAs + 2 reads five times, then the MFMAs left
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
+            slot_barrier();
+            // ---- L_B
+            issue_b(0); issue_b(1); ++kb;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) af[t][kh] = fa(ua_hi, t, kh);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // B(k+1) landed
+            slot_barrier();
+            // ---- C_B
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mma4(4 + t, t, kh);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // AL(k+1) landed
+            slot_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the out-of-range pieces past the split's end
+    }
+#else
     int P = 0, p_s = 0, pp = 0;                         // pp: the producer's pair slot
     auto issue_pair = [&](const int J0) {              // J0 = 0 -> (AL, BL), J0 = 2 -> (BH, AH) of K tile p_s
         if (P >= total_u) return;
@@ -135,11 +240,6 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
     wait_vm_n(min(R10 ? 10 : 6, 2 * max(0, total_u - 3))); // units 0..2 landed (own pieces)
     slot_barrier();
 
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int U0 = 0, c0 = 0, c1 = 1;                 // c0 / c1: pair slots of the current K tile's (AL, BL) / (BH, AH)
 
     if (wm == 1) slot_barrier();               // stagger: waves 4..7 run one slot behind
@@ -198,6 +298,7 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
         slot_barrier();
         U0 += 4;
     }
+#endif
     if (wm == 0) slot_barrier();               // re-align the two groups
 
     // ---- epilogue: fp32 partial tile, wave-local 16-row passes through this wave's slab -----------------
