@@ -11,14 +11,18 @@
 //   O^T = V^T P^T    the S^T accumulators ARE the B operand (k-slot (g,j) <-> key
 //                    32s + 16(j>>2) + 4g + (j&3)); A = V read transposed from its row-major LDS
 //                    image (ds_read_b64_tr_b16 for bf16).
-// One wavefront owns 32 queries for the whole kernel; the 4 wavefronts of a workgroup share the
-// K/V images; keys stream through LDS in chunks of 128 with online-softmax rescaling, so any P
-// works (197 -> 2 chunks, 362 -> 3).
-//
-// Backward = two kernels that recompute P from the saved log-sum-exp:
-//   sattn_bwd_dq : same geometry as forward; dS^T = P^T o (dP^T - delta) ; dQ^T += K^T dS^T
-//   sattn_bwd_dkv: one wavefront owns 32 keys; queries stream through LDS;
-//                  dV^T += dO^T P ; dK^T += Q^T dS
+// Kernels in this file (bfloat16; float32 runs the same templates with 4 wavefronts x 32 queries):
+//   * sattn_fwd_kernel: 8 wavefronts x 16 queries per workgroup, keys stream through two LDS images in chunks of 128 with
+//     online-softmax rescaling (any P: 197 -> 2 chunks, 362 -> 3).  RES variant (128 < P <= 256): ONE workgroup per
+//     (frame, head) keeps all keys / values resident and walks the query blocks itself.
+//   * attn_spatial_pers.h (round 4): the persistent forward for 128 < P <= 240 -- one 16-wavefront workgroup per CU walks
+//     the (frame, head) problems, the next problem's K / V arriving by LDS-DMA under the current one's arithmetic.
+//   * backward, recomputing P from the saved (row max, 1 / row sum):
+//       sattn_bwd_dq  : the forward's geometry; dS^T = P^T o (dP^T - delta); dQ^T += K^T dS^T
+//       sattn_bwd_dkv : one wavefront owns 32 keys, queries stream through LDS; dV^T += dO^T P; dK^T += Q^T dS
+//       sattn_bwd_fused_kernel (RES, round 3): both parts in ONE workgroup per (frame, head) -- dQ with K / V in LDS, a
+//       barrier, dK / dV with Q / dO in the same bytes, the second part's images written from the fragments the first part
+//       loaded: every operand is read from global memory once.
 #include "common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -796,6 +800,8 @@ __global__ __launch_bounds__(512) void sattn_bwd_fused_kernel(const T* __restric
     sattn_dkv_body<T, DH, 1, FP8, true, true>(qkv, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
 }
 
+#include "attn_spatial_pers.h"
+
 // ------------------------------------------------------------------------------------------
 #define DISPATCH_DH(DHV, ...)                                   \
     do {                                                        \
@@ -831,6 +837,40 @@ extern "C" int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, lo
     dim3 grid((P + 127) / 128, BF * heads);
     // bf16: 8 wavefronts x 16 queries (more wavefronts per SIMD); fp32 keeps 4 x 32 (its LDS image fills the CU)
     if (dtype == DT_BF16) {
+        static const int pers = istvt_tune("ISTVT_SATTN_PERS", 1);
+        // (P <= 240: at least one of the 16 wavefronts owns no query tile and does the staging; with all 16 busy -- P = 256:
+        //  114 us against 93 -- the keys-resident kernel below is faster)
+        if (pers && dh == 64 && P > CHUNK && P <= 240 && ldqkv * 2 * P < 0x7fffffffL) {
+            // persistent form: one 16-wavefront workgroup per CU walks the (frame, head) problems, the next problem's K / V
+            // arriving by LDS-DMA under the current one's arithmetic (attn_spatial_pers.h)
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+                cus = n;
+            }
+            const int nprob = BF * heads, ntt = (P - CHUNK + 15) / 16;
+            const dim3 pgrid(nprob < cus ? nprob : cus);
+#define SP_LAUNCH(NTTV)                                                                                                   \
+            case NTTV: {                                                                                                  \
+                static bool attr_set = false;                                                                              \
+                if (!attr_set) {                                                                                           \
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sattn_fwd_pers_kernel<64, NTTV>),                \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * spers::IMG_B) != hipSuccess)   \
+                        return ISTVT_ERR_LAUNCH;                                                                           \
+                    attr_set = true;                                                                                       \
+                }                                                                                                          \
+                hipLaunchKernelGGL((sattn_fwd_pers_kernel<64, NTTV>), pgrid, dim3(1024), 4 * spers::IMG_B, stream,          \
+                                   (const bf16_t*)qkv, (bf16_t*)out, lse, nprob, P, heads, scale, ldqkv, ldo);            \
+            } break;
+            switch (ntt) {
+                SP_LAUNCH(1) SP_LAUNCH(2) SP_LAUNCH(3) SP_LAUNCH(4) SP_LAUNCH(5) SP_LAUNCH(6) SP_LAUNCH(7) SP_LAUNCH(8)
+                default: return ISTVT_ERR_SHAPE;
+            }
+#undef SP_LAUNCH
+            return istvt_check_launch();
+        }
         if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {      // one workgroup per (frame, head), keys resident (P = 197 at 224^2)
             DISPATCH_DH(dh, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, false, true>), false, (const bf16_t*)qkv, (bf16_t*)out, lse,
                                        P, heads, scale, ldqkv, ldo));
