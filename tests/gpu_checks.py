@@ -19,6 +19,17 @@ from istvt_amd import ops  # noqa: E402
 
 DEV = 'cuda'
 TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+# The benchmarked bf16 attention / LayerNorm kernels against fp64 ON THE SAME bf16 inputs: what separates them is one
+# rounding of the result to bfloat16 (2^-9 relative worst case, ~1.7e-3 as a norm-wise error) plus, in the attention
+# kernels, one rounding of the probabilities / score gradients before their second MFMA.  Measured on MI355X (round 4):
+# LayerNorm 1.66e-3, spatial attention 2.4-2.5e-3, temporal attention 2.3-2.4e-3 (every variant, forward and all
+# gradients, F = 2..17, P = 37..362), sampled production shapes up to 3.3e-3.  Rounds 1-3 held them to 2e-2 / 4e-2.
+TOL_BF16_ONE_ROUNDING = 4e-3
+TOL_BF16_PRODUCTION = 5e-3
+
+
+def tol_rounding(dtype):
+    return TOL[dtype] if dtype == torch.float32 else TOL_BF16_ONE_ROUNDING
 
 
 def relerr(a, b):
@@ -150,7 +161,7 @@ def layernorm(dtype, D=728, M=1003, pad=False):
     dx4 = ops.layernorm_bwd(dy, x, mean, rstd, g, dg4, db4, pad=pad, dcol=dcol4)
     e = max(e, relerr(dx3, xd.grad), relerr(dg3, gd.grad), relerr(db3, bd.grad), relerr(dx4, dx3), relerr(dg4, dg3),
             relerr(dcol4, xd.grad.sum(0)))
-    return e, TOL[dtype]
+    return e, tol_rounding(dtype)
 
 
 def _diff_ref(y, B, F, P):
@@ -206,7 +217,7 @@ def attn_spatial(dtype, BF=3, P=197, heads=8, dh=64, pad=False):
     dqkv = ops.attn_spatial_bwd(qkv, out, padded(dout) if pad else dout, lse, BF, P, heads, dh)
     e_f = relerr(out, ref)
     e_b = max(relerr(a, b) for a, b in zip(dqkv.chunk(3, dim=-1), qd.grad.chunk(3, dim=-1)))
-    return max(e_f, e_b), TOL[dtype]
+    return max(e_f, e_b), tol_rounding(dtype)
 
 
 def attn_spatial_fp8(BF=3, P=197, heads=8, dh=64):
@@ -268,7 +279,7 @@ def attn_temporal(dtype, B=2, F=9, P=37, heads=8, dh=64, pad=False, diff=False, 
         dqk, dv = dqk[:, :2 * inner], dqk[:, 2 * inner:]
     e = max(relerr(out, ref), relerr(dqk, qkd.grad), relerr(dv, vd.grad))
     # bf16 + diff: the kernel rounds q[f] - q[f-1] to bf16 once more before the MFMA (operand type)
-    return e, TOL[dtype] * (2 if (diff == 1 and dtype == torch.bfloat16) else 1)
+    return e, tol_rounding(dtype)
 
 
 def layernorm_diff(dtype, B=3, F=9, P=23, D=728):
@@ -284,7 +295,7 @@ def layernorm_diff(dtype, B=3, F=9, P=23, D=728):
     y0, _, _ = ops.layernorm_fwd(x, g, b, 1e-5, pad=True)
     planes_ok = yd.data_ptr() + M * yd.stride(0) * yd.element_size() == y.data_ptr()
     e = max(relerr(y, ref), relerr(yd, dref), 0.0 if torch.equal(y, y0) else 1.0, 0.0 if planes_ok else 1.0)
-    return e, TOL[dtype]
+    return e, tol_rounding(dtype)
 
 
 def gemm_a_select(M=3000, K=728, N=1536, split=1024):
@@ -909,7 +920,7 @@ def attn_spatial_production(BF=2304, P=197, heads=8, dh=64, nsample=40):
         worst = max(worst, relerr(out[rows, h * dh:(h + 1) * dh].cpu(), ref.detach()))
         for j, t in enumerate((q, k, v)):
             worst = max(worst, relerr(dqkv[rows, j * inner + h * dh: j * inner + (h + 1) * dh].cpu(), t.grad))
-    return worst, TOL[dt]
+    return worst, TOL_BF16_PRODUCTION
 
 
 def attn_temporal_production(B=32, F=9, P=197, heads=8, dh=64, nsample=256):
@@ -948,7 +959,7 @@ def attn_temporal_production(B=32, F=9, P=197, heads=8, dh=64, nsample=256):
         ref.backward(do4[b, :, p, cs].double().cpu())
         worst = max(worst, relerr(o4[b, :, p, cs].cpu(), ref.detach()), relerr(dqk4[b, :, p, cs].cpu(), q.grad),
                     relerr(dqk4[b, :, p, inner + h * dh: inner + (h + 1) * dh].cpu(), k.grad), relerr(dv4[b, :, p, cs].cpu(), vv.grad))
-    return worst, 2 * TOL[dt]
+    return worst, TOL_BF16_PRODUCTION
 
 
 def conv_dense_many_chunks(Fr=8, S_=224):

@@ -439,6 +439,22 @@ def test_g5_native_bf16_vs_reference_golden(golden_dir):
     live = [str(s) for s in g['live_param_names']]
     assert sorted(k for k, p in named.items() if p.grad is not None) == sorted(live)
     assert all(torch.isfinite(named[k].grad).all() for k in live)
+    # Gradient norms against the reference's 252 captured ones.  What bfloat16 can promise on THIS
+    # fixture is limited -- measured on MI355X (round 4, tmp script g5bf16.py): the head and the final LayerNorm 0.877 of
+    # the reference norm (the logit itself is 3 % off and the loss gradient follows), the feed-forward and spatial-attention
+    # weights 0.28 ... 2.3, the temporal block 0.002 ... 813 (to_qk) and its LayerNorm 0.1 ... 46: the recipe's
+    # sin-wave weights drive the temporal scores to ~50, where one bf16 rounding of a score moves a probability by a
+    # factor, and every layer below inherits it.  So: tight where the model is well-conditioned, a factor where it is
+    # not, nothing for the temporal block -- whose bf16 gradients are held to cosine > 0.97 / norms within 15 % on
+    # well-conditioned weights by test_depth12_fp32_and_bf16_vs_oracle, the configuration bench.py runs.
+    ratio = {k: float(named[k].grad.float().norm()) / float(g['gnorm.' + k]) for k in live if float(g['gnorm.' + k]) > 0}
+    for k, r in ratio.items():
+        if k.startswith(('vit.mlp_head', 'vit.transformer.norm')):
+            assert 0.75 < r < 1.25, (k, r)
+        elif '.1.fn.' in k or '.2.fn.' in k:             # spatial attention and feed-forward weights of every layer
+            assert 0.2 < r < 3.0, (k, r)
+        elif k.startswith('xcep.'):
+            assert 0.12 < r < 1.2, (k, r)
 
 
 def _bucket_grads(model):
