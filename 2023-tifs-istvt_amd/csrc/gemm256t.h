@@ -45,6 +45,26 @@
 #define ISTVT_T_SCHED 1
 #endif
 
+#ifdef ISTVT_T_STAMP
+// diagnostic build (-DISTVT_T_STAMP): per-segment s_memtime sums of the round-4 schedule, [workgroup][wavefront][16] u64 =
+// 12 segments as in gemm256q.h's DBG 256, K-loop cycles, K-loop 100 MHz ticks, K tiles, -; tools/gemm_t_slots.py
+__device__ unsigned long long* g_t_stamps = nullptr;
+extern "C" int istvt_diag_t_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_t_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -4;
+}
+#define T_STAMP(i)                                                                                    \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((i) > 0 || kt > 0) ts_seg[((i) + 11) % 12] += (unsigned)(t_ - ts_prev);                   \
+        ts_prev = t_;                                                                                 \
+    } while (0)
+#else
+#define T_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int tswz(int k) { return 2 * ((k & 3) | (((k >> 3) & 1) << 2)); }
 
 // fragment of 8 consecutive k (k0 .. k0+7) for column col16 + r out of a [64][128] unit image
@@ -149,6 +169,12 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // B(0), AL(0) landed (own pieces)
         slot_barrier();
         if (wm == 1) slot_barrier();                       // stagger: waves 4..7 run one slot behind
+#ifdef ISTVT_T_STAMP
+        unsigned ts_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long ts_prev = 0;
+        const unsigned long long ts_c0 = __builtin_amdgcn_s_memtime(), ts_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
         for (int kt = 0; kt < nkt; ++kt) {
             const char* ubase = smem + (kt & 1) * 4 * QU_BYTES;
             const char* ua_lo = ubase;
@@ -165,14 +191,19 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
                 return (ISTVT_T_DIAG & 2) ? diag_frag(lane + t + kh) : t_frag(base, kh * 32 + 8 * g, wm * 64 + t * 16, r);
             };
             // ---- L_A
+            T_STAMP(0);
             issue_a(0); issue_a(1); ++ka;
+            T_STAMP(1);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh)
                     bq[t][kh] = (ISTVT_T_DIAG & 2) ? diag_frag(lane - t - kh) : t_frag(ub, kh * 32 + 8 * g, (wn & 1) * 64 + t * 16, r);
+            T_STAMP(2);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // AH(k) landed
+            T_STAMP(3);
             slot_barrier();
+            T_STAMP(4);
             // ---- C_A: the A fragments (i: t = i & 3, kh = i >> 2) two ahead of the MFMAs that use them
             af[0][0] = fa(ua_lo, 0, 0);
             af[1][0] = fa(ua_lo, 1, 0);
@@ -191,23 +222,42 @@ __device__ __forceinline__ void gemm256t_body(const GemmArgs& p, const int wg, c
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
             }
+            T_STAMP(5);
             slot_barrier();
+            T_STAMP(6);
             // ---- L_B
             issue_b(0); issue_b(1); ++kb;
+            T_STAMP(7);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) af[t][kh] = fa(ua_hi, t, kh);
+            T_STAMP(8);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // B(k+1) landed
+            T_STAMP(9);
             slot_barrier();
+            T_STAMP(10);
             // ---- C_B
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) mma4(4 + t, t, kh);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // AL(k+1) landed
+            T_STAMP(11);
             slot_barrier();
         }
+#ifdef ISTVT_T_STAMP
+        {
+            const unsigned long long ts_c1 = __builtin_amdgcn_s_memtime(), ts_r1 = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (lane == 0 && g_t_stamps && blockIdx.x < 256) {
+                unsigned long long* d = g_t_stamps + ((long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) d[j] = ts_seg[j];
+                d[12] = ts_c1 - ts_c0; d[13] = ts_r1 - ts_r0; d[14] = nkt; d[15] = 1;
+            }
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the out-of-range pieces past the split's end
     }
 #else
