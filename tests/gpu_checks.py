@@ -298,6 +298,27 @@ def layernorm_diff(dtype, B=3, F=9, P=23, D=728):
     return e, tol_rounding(dtype)
 
 
+def gemm_cu_reserve(M=56736, K=728, N=1536):
+    """ops.set_cu_reserve (the persistent GEMMs leave CUs to a collective in flight, parallel.GradBucket): another grid and
+    tile deal, the same bits -- every output tile is computed by exactly one workgroup in one fixed order"""
+    dt = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = ops.empty_rows(M, K, dt, DEV, True); x.copy_(torch.randn((M, K), generator=g, device=DEV))
+    w = ops.empty_rows(N, K, dt, DEV, True); w.copy_(torch.randn((N, K), generator=g, device=DEV) * K ** -0.5)
+    b = torch.randn((N,), generator=g, device=DEV)
+    res = ops.empty_rows(M, N, dt, DEV, True); res.copy_(torch.randn((M, N), generator=g, device=DEV))
+    base = [ops.linear_fwd(x, w, pad=True), ops.linear_fwd(x, w, b, res, pad=True)]
+    worst = 0.0
+    for reserve in (32, 64, 100):
+        prev = ops.set_cu_reserve(reserve)
+        try:
+            got = [ops.linear_fwd(x, w, pad=True), ops.linear_fwd(x, w, b, res, pad=True)]
+        finally:
+            ops.set_cu_reserve(prev)
+        worst = max(worst, *[0.0 if torch.equal(a_, b_) else 1.0 for a_, b_ in zip(base, got)])
+    return worst, 0.0
+
+
 def gemm_a_select(M=3000, K=728, N=1536, split=1024):
     """istvt_gemm flags bit 1: columns < split from plane 0, the rest from plane 1 of a two-plane A (integer-exact)"""
     dt = torch.bfloat16
@@ -989,6 +1010,7 @@ def all_checks():  # noqa: F811
     out.append(('layernorm_diff_bf16', lambda: layernorm_diff(torch.bfloat16)))
     out.append(('layernorm_diff_f32', lambda: layernorm_diff(torch.float32)))
     out.append(('layernorm_diff_F17_bf16', lambda: layernorm_diff(torch.bfloat16, 2, 17, 197)))
+    out.append(('gemm_cu_reserve_bit_identical', gemm_cu_reserve))
     out.append(('gemm_a_select', gemm_a_select))
     out.append(('gemm_a_select_tall', lambda: gemm_a_select(56736, 728, 1536, 1024)))
     out.append(('attn_temporal_production_C4', lambda: attn_temporal_production(16, 17, 197, 8, 64, 128)))

@@ -409,3 +409,13 @@ def test_bench_accepts_the_reference_training_flags(monkeypatch):
         parse('-bz', '15', '-d', '0,1')
     with pytest.raises(SystemExit):
         parse('--gpus', '4', '-d', '0,1')
+
+
+def test_cu_reserve_entry_point(pkg):
+    """istvt_set_cu_reserve is host-side state of the library: returns the previous value, refuses nonsense (no GPU needed)"""
+    from istvt_amd import _lib
+    lib = _lib.lib()
+    assert lib.istvt_set_cu_reserve(32) == 0
+    assert lib.istvt_set_cu_reserve(0) == 32
+    assert lib.istvt_set_cu_reserve(-1) < 0 and lib.istvt_set_cu_reserve(10000) < 0
+    assert lib.istvt_set_cu_reserve(0) == 0
