@@ -593,6 +593,57 @@ __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in,
     }
 }
 
+// dw_load_tile in two halves, for a caller that keeps the NEXT tile's global loads in flight under the current tile's
+// arithmetic (dwconv3x3_wgrad_kernel, round 4): fetch = every global load of the tile into registers, commit = BatchNorm
+// pack / ReLU / conversion and the (swizzled, float) LDS stores.
+constexpr int DW_NIT = (DW_LH * DW_LW * DW_NCH + 255) / 256;
+template <typename T> struct DwTileRegs { typename Mma<T>::frag raw[DW_NIT]; unsigned ok; };
+template <typename T>
+__device__ __forceinline__ void dw_tile_fetch(DwTileRegs<T>& rg, const T* __restrict__ in, long f, int y0, int x0, int c0,
+                                              int H, int W, int C, int tid) {
+    constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
+    const int ch = tid % DW_NCH, c = c0 + ch * 8;
+    rg.ok = 0u;
+#pragma unroll
+    for (int it = 0; it < DW_NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
+        if (ok) { rg.raw[it] = frag_load(in + ((f * H + y) * W + x) * C + c); rg.ok |= 1u << it; }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void dw_tile_commit(float* tile, const DwTileRegs<T>& rg, bool bnp, const float (&mu)[8],
+                                               const float (&sc)[8], const float (&be)[8], int relu, int tid) {
+    constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
+    static_assert(DW_LW % 2 == 0, "swizzled tile: even row pitch");
+    const int ch = tid % DW_NCH;
+#pragma unroll
+    for (int it = 0; it < DW_NIT; ++it) {
+        const int i = tid + 256 * it;
+        if (i >= NVEC) continue;
+        const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (rg.ok & (1u << it)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = Mma<T>::get(rg.raw[it], j);
+            if (bnp) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu[j]) * sc[j] + be[j];
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+        }
+        float* dst = tile + (py * DW_LW + px) * DW_CC + ch * 8;
+        const int o = (px & 1) * 4;
+        *reinterpret_cast<float4*>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4 - o) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // Items of a thread in dwconv3x3_kernel: FOUR VERTICALLY ADJACENT pixels of one column (a 4 x 1 strip) and one 8-channel
 // chunk.  The strip's 12 (item, vertical tap) pairs touch only 6 distinct input rows, so per horizontal tap a thread
 // reads (and converts to float) 6 chunks instead of 12: half the LDS reads and half the bf16 -> float conversions of a
@@ -618,10 +669,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
     // channel chunks) are dispatched back to back and meet in L2 instead of re-fetching from HBM
     const int nch = (p.C + DW_CC - 1) / DW_CC;
     const int bid = xcd_chunk(blockIdx.x, gridDim.x);    // an XCD's workgroups: a contiguous run of tiles (shared halos)
-    const long t = bid / nch;
-    const int c0 = (int)(bid % nch) * DW_CC;
-    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
-    const long f = t / (tiles_x * tiles_y);
+    // 32-bit tile arithmetic (the host checks the tile count): as `long` the three divisions were ~130 instructions each
+    const unsigned t = (unsigned)bid / (unsigned)nch;
+    const int c0 = (int)((unsigned)bid - t * nch) * DW_CC;
+    const unsigned tpf = (unsigned)(tiles_x * tiles_y), fu = t / tpf, tr = t - fu * tpf;
+    const int ty = (int)(tr / (unsigned)tiles_x), tx = (int)(tr - ty * (unsigned)tiles_x);
+    const long f = fu;
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
 #ifdef ISTVT_DW_DIAG
     unsigned long long tstamp[5];
@@ -840,6 +893,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
 }
 
 // dw[c][tap] += sum_pix dout[pix][c] * a[pix + tap][c],  a = on-load transform of the forward input
+#ifdef ISTVT_DW_STAMP
+// diagnostic build (-DISTVT_DW_STAMP): per-phase s_memtime sums of the depthwise weight-gradient kernel per wavefront,
+// [workgroup][wavefront][8] u64 = {top barrier, issue loads, tile landed + transformed + stored, barrier, FMAs, tiles, -, -}
+__device__ unsigned long long* g_dw_stamps = nullptr;
+extern "C" int istvt_diag_dw_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dw_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -4;
+}
+#define DW_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if ((i) > 0) dws_seg[(i) - 1] += (unsigned)(t_ - dws_prev);                                   \
+        dws_prev = t_;                                                                                \
+    } while (0)
+#else
+#define DW_STAMP(i) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ in, const float* in_bn,
                                                               int in_relu,
@@ -854,10 +927,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     __shared__ float sred[4][DW_NCH][72];
     const int tid = threadIdx.x;
     const int tiles_x = (W + DW_TW - 1) / DW_TW, tiles_y = (H + DW_TH - 1) / DW_TH;
-    const long ntiles = (long)Fr * tiles_x * tiles_y;
+    // 32-bit tile arithmetic (the host checks the tile count): as `long`, five divisions per tile were ~650 of the tile
+    // loop's ~1800 instructions
+    const unsigned tpf = (unsigned)(tiles_x * tiles_y), ntiles = (unsigned)Fr * tpf;
     const int nch = (C + DW_CC - 1) / DW_CC;                 // 1-D grid, channel chunk fastest (L2 sharing)
     const int bid = xcd_chunk(blockIdx.x, gridDim.x);
-    const int c0 = (int)(bid % nch) * DW_CC;
+    const unsigned slot = (unsigned)bid / (unsigned)nch;
+    const int c0 = (int)((unsigned)bid - slot * nch) * DW_CC;
     const int ch = tid % DW_NCH, c = c0 + ch * 8;
     const int o0 = ((tid / DW_NCH) & 1) * 4;         // parity of this thread's pixel column (DW_PIXSTEP and DW_TW are even)
     float acc[9][8];
@@ -865,52 +941,105 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    for (long t = bid / nch; t < ntiles; t += gridDim.x / nch) {
-        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
-        const long f = t / (tiles_x * tiles_y);
+#ifdef ISTVT_DW_STAMP
+    unsigned dws_seg[5] = {0, 0, 0, 0, 0}, dws_n = 0;
+    unsigned long long dws_prev = 0;
+#endif
+    // Round 4 (stamps: tools/dw_stamps.py, profiles/r04_e_dwconv_wgrad_stamps.txt).  A tile cost a wavefront ~7.4 k
+    // cycles: 4.2 k from issuing the tile's global loads to its LDS stores (HBM round trip + a per-tile re-read of the
+    // BatchNorm pack, each waited for; nothing overlapped inside a workgroup and two workgroups per CU), 2.3 k of FMAs.
+    // Three changes, measured one at a time on one box (H=109 C=64 / H=109 C=128 / H=55 C=256 / H=28 C=728, us):
+    //   next tile's loads (input tile AND output-gradient rows) requested BEFORE the current tile's FMAs, waiting in
+    //   registers (+40 VGPRs) -- alone: 224 -> 231 (the round trip moved, the BatchNorm re-read stayed exposed);
+    //   BatchNorm pack read once per workgroup (its channels never change):           226 / 434 / 245 / 207 -> 222 / 420 / 236 / 196;
+    //   vertical strips (18 LDS positions per thread and tile instead of 36):         -> 208 / 404 / 227 / 190.
+    // (Strips alone, without the prefetch, had measured neutral: the exposed round trip hid the LDS reads.)  A tile now
+    // costs ~6.4 k cycles: 2.0 k transform + LDS stores, 4.1 k next-tile load issue + FMAs + the end-of-tile wait.
+    const unsigned tstep = gridDim.x / (unsigned)nch;
+    int wstrip, wpx;
+    dw_strip(tid, wstrip, wpx);
+    // the BatchNorm pack of the workgroup's channels: the same for every tile, read once (it was re-read, and waited for,
+    // per tile)
+    float bn_mu[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bn_sc[8] = {1, 1, 1, 1, 1, 1, 1, 1}, bn_be[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (in_bn && c < C) { load8(in_bn + c, bn_mu); load8(in_bn + 2 * C + c, bn_sc); load8(in_bn + 3 * C + c, bn_be); }
+    DwTileRegs<T> nxt;
+    typename Mma<T>::frag ndraw[DW_ITEMS];
+    unsigned nlive = 0;                                      // bit k: item k of the fetched tile is inside the image
+    auto fetch = [&](unsigned t) {
+        const unsigned fu = t / tpf, tr = t - fu * tpf;
+        const int ty = (int)(tr / (unsigned)tiles_x), tx = (int)(tr - ty * (unsigned)tiles_x);
+        const long f = fu;
         const int y0 = ty * DW_TH, x0 = tx * DW_TW;
-        __syncthreads();
-        // the output-gradient rows of this thread's items are requested BEFORE the tile is staged: issued after the
-        // barrier they were a second exposed HBM latency per tile
+        nlive = 0;
+#pragma unroll
+        for (int k = 0; k < DW_ITEMS; ++k) {
+            const int y = y0 + wstrip * DW_ITEMS + k, x = x0 + wpx;
+            if (y < H && x < W && c < C) { ndraw[k] = frag_load(dout + ((f * H + y) * W + x) * C + c); nlive |= 1u << k; }
+        }
+#ifdef ISTVT_DW_CACHE_DIAG
+        dw_tile_fetch<T>(nxt, in, 0, 0, 0, c0, H, W, C, tid);
+#else
+        dw_tile_fetch<T>(nxt, in, f, y0, x0, c0, H, W, C, tid);
+#endif
+    };
+    if (slot < ntiles) fetch(slot);
+    for (unsigned t = slot; t < ntiles; t += tstep) {
+        DW_STAMP(0);
+        __syncthreads();                                   // the previous tile's FMAs are done reading the LDS tile
+        DW_STAMP(1);
         typename Mma<T>::frag draw[DW_ITEMS];
 #pragma unroll
-        for (int k = 0; k < DW_ITEMS; ++k) {
-            const int pix = tid / DW_NCH + DW_PIXSTEP * k;
-            const int y = y0 + pix / DW_TW, x = x0 + pix % DW_TW;
-            if (y < H && x < W && c < C) draw[k] = frag_load(dout + ((f * H + y) * W + x) * C + c);
-        }
-        dw_load_tile<T, float, true>(tile, in, f, y0, x0, c0, H, W, C, in_bn, in_relu, tid);
+        for (int k = 0; k < DW_ITEMS; ++k) draw[k] = ndraw[k];
+        const unsigned dlive = nlive;
+        dw_tile_commit<T>(tile, nxt, in_bn != nullptr, bn_mu, bn_sc, bn_be, in_relu, tid);
+        DW_STAMP(2);
         __syncthreads();
+        DW_STAMP(3);
+        if (t + tstep < ntiles) fetch(t + tstep);          // in flight under the FMAs below (t + tstep < 2^32: host check)
+        DW_STAMP(4);
+        {
+            // vertical strips (dw_strip, as in dwconv3x3_kernel): a thread's four items are four consecutive rows of one
+            // column, so the 12 (item, vertical tap) pairs of a horizontal tap share 6 input rows -- 18 LDS positions per
+            // thread and tile instead of 36
+            float d[DW_ITEMS][8];
 #pragma unroll
-        for (int k = 0; k < DW_ITEMS; ++k) {
-            const int pix = tid / DW_NCH + DW_PIXSTEP * k;
-            const int py = pix / DW_TW, px = pix % DW_TW;
-            const int y = y0 + py, x = x0 + px;
-            if (y >= H || x >= W || c >= C) continue;
-            float d[8];
-            if constexpr (sizeof(T) == 2) {
+            for (int k = 0; k < DW_ITEMS; ++k) {
+                const bool live = (dlive >> k) & 1u;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = (float)draw[k][j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = draw[k].v[j];
+                for (int j = 0; j < 8; ++j) d[k][j] = live ? Mma<T>::get(draw[k], j) : 0.f;
             }
+            const float* tbase = tile + ((wstrip * DW_ITEMS) * DW_LW + wpx) * DW_CC + ch * 8;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int o = (dx & 1) ? 4 - o0 : o0;       // swizzled tile: halves swapped in odd LDS pixels
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    // swizzled tile (dw_load_tile<.., SWZ>): halves swapped in odd LDS pixels; px + dx has the parity of
-                    // the thread's pixel for dx = 0, 2 and the other one for dx = 1
-                    const float* tp = tile + ((py + dy) * DW_LW + px + dx) * DW_CC + ch * 8;
-                    const int o = (dx & 1) ? 4 - o0 : o0;
+                for (int r = 0; r < DW_ITEMS + 2; ++r) {
+                    const float* tp = tbase + (r * DW_LW + dx) * DW_CC;
                     const float4 lo = *reinterpret_cast<const float4*>(tp + o);
                     const float4 hi = *reinterpret_cast<const float4*>(tp + 4 - o);
                     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[dy * 3 + dx][j] += d[j] * v[j];
+                    for (int k = 0; k < DW_ITEMS; ++k) {
+                        const int dy = r - k;
+                        if (dy < 0 || dy > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[dy * 3 + dx][j] += d[k][j] * v[j];
+                    }
                 }
+            }
         }
+        DW_STAMP(5);
+#ifdef ISTVT_DW_STAMP
+        ++dws_n;
+#endif
     }
+#ifdef ISTVT_DW_STAMP
+    if ((tid & 63) == 0 && g_dw_stamps && blockIdx.x < 2048) {
+        unsigned long long* dd = g_dw_stamps + ((long)blockIdx.x * 4 + (tid >> 6)) * 8;
+        for (int j = 0; j < 5; ++j) dd[j] = dws_seg[j];
+        dd[5] = dws_n;
+    }
+#endif
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -932,7 +1061,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
         // one partial [C][9] slab per slot (the workgroups of a slot cover the channel chunks): folded in slot order by
         // istvt_rows_reduce_add -- no float atomics
         if (cc < C)
-            dw[(long)(bid / nch) * C * 9 + (long)cc * 9 + tap] = (sred[0][chunk][rem] + sred[1][chunk][rem]) + (sred[2][chunk][rem] + sred[3][chunk][rem]);
+            dw[(long)slot * C * 9 + (long)cc * 9 + tap] = (sred[0][chunk][rem] + sred[1][chunk][rem]) + (sred[2][chunk][rem] + sred[3][chunk][rem]);
     }
 }
 
@@ -983,6 +1112,7 @@ extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_
     const int cy = (C + DW_CC - 1) / DW_CC;
     const long bx = dww_slots(Fr, H, W, C);
     if (ws_elems < bx * C * 9) return ISTVT_ERR_SHAPE;
+    if ((long)Fr * ((H + DW_TH - 1) / DW_TH) * ((W + DW_TW - 1) / DW_TW) + bx > 0x7fffffffL) return ISTVT_ERR_SHAPE;   // 32-bit tile index
     dim3 grid((unsigned)(bx * cy));                        // slot-major, channel chunk fastest
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), grid, dim3(256), 0, stream, (const T*)in,
                                              in_bn, in_relu, (const T*)dout, ws, Fr, H, W, C));
@@ -1000,13 +1130,17 @@ __global__ __launch_bounds__(256) void pool_add_fwd_kernel(const T* __restrict__
                                                            const T* __restrict__ skip, const float* __restrict__ bns,
                                                            T* __restrict__ out, uint8_t* __restrict__ argmax, long Mo,
                                                            int H, int W, int C, int Ho, int Wo) {
-    const int vpr = C / 8;
-    const long nitems = Mo * vpr, stride = (long)gridDim.x * 256;
-    for (long i = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < nitems; i += stride) {   // windows of neighbouring rows overlap: keep them in one XCD's L2
-        const int ch = (int)(i % vpr);
-        const long m = i / vpr;
-        const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
-        const long f = m / ((long)Wo * Ho);
+    // Item -> (frame, row, column, chunk) in 32-bit unsigned arithmetic (the launcher refuses 2^31 items or more): as
+    // `long` the four divisions were the compiler's 64-bit expansion with a run-time test for the 32-bit case, per item,
+    // in a kernel whose issue port is as busy as its memory path.
+    const unsigned vpr = C / 8;
+    const unsigned nitems = (unsigned)Mo * vpr, stride = gridDim.x * 256u;
+    for (unsigned i = (unsigned)xcd_chunk(blockIdx.x, gridDim.x) * 256u + threadIdx.x; i < nitems; i += stride) {   // windows of neighbouring rows overlap: keep them in one XCD's L2
+        const unsigned mu_ = i / vpr, ru_ = mu_ / (unsigned)Wo, fu_ = ru_ / (unsigned)Ho;
+        const int ch = (int)(i - mu_ * vpr);
+        const long m = mu_;
+        const int xo = (int)(mu_ - ru_ * (unsigned)Wo), yo = (int)(ru_ - fu_ * (unsigned)Ho);
+        const long f = fu_;
         // All nine taps (clamped addresses) and the skip row are requested before any is used: with each load inside its
         // bounds test the taps were nine dependent global-memory latencies per output (2.2 TB/s of algorithmic traffic).
         typename Mma<T>::frag raw[9];
@@ -1079,9 +1213,12 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mu[j] = 0.f; rs[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; }
     if (stats && t < nthr) { load8(bnp + ch * 8, mu); load8(bnp + C + ch * 8, rs); }
-    for (long q = t < nthr ? t / vpr : nquads; q < nquads; q += nthr / vpr) {
-        const int b = (int)(q % QW), a = (int)((q / QW) % QH);
-        const long f = q / ((long)QW * QH);
+    // quad -> (frame, a, b) in 32-bit unsigned arithmetic (the launcher refuses 2^31 quads or more), see pool_add_fwd_kernel
+    const unsigned qstep = (unsigned)(nthr / vpr), nq = (unsigned)nquads;
+    for (unsigned q = t < nthr ? (unsigned)(t / vpr) : nq; q < nq; q += qstep) {
+        const unsigned ru_ = q / (unsigned)QW, fu_ = ru_ / (unsigned)QH;
+        const int b = (int)(q - ru_ * (unsigned)QW), a = (int)(ru_ - fu_ * (unsigned)QH);
+        const long f = fu_;
         // windows (a-1+wa, b-1+wb), wa, wb in {0, 1}
         typename Mma<T>::frag draw[4], uraw[4];
         unsigned lo[4], hi[4];
@@ -1163,13 +1300,14 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ dou
 template <typename T>
 __global__ __launch_bounds__(256) void subsample2_kernel(const T* __restrict__ in, T* __restrict__ out, long Mo, int H,
                                                          int W, int C, int Ho, int Wo) {
-    const int vpr = C / 8;
-    const long nitems = Mo * vpr, stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nitems; i += stride) {
-        const int ch = (int)(i % vpr);
-        const long m = i / vpr;
-        const int xo = (int)(m % Wo), yo = (int)((m / Wo) % Ho);
-        const long f = m / ((long)Wo * Ho);
+    const unsigned vpr = C / 8;
+    const unsigned nitems = (unsigned)Mo * vpr, stride = gridDim.x * 256u;      // 32-bit: the launcher checks the count
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nitems; i += stride) {
+        const unsigned mu_ = i / vpr, ru_ = mu_ / (unsigned)Wo, fu_ = ru_ / (unsigned)Ho;
+        const int ch = (int)(i - mu_ * vpr);
+        const long m = mu_;
+        const int xo = (int)(mu_ - ru_ * (unsigned)Wo), yo = (int)(ru_ - fu_ * (unsigned)Ho);
+        const long f = fu_;
         float v[8];
         load8(in + ((f * H + 2 * yo) * W + 2 * xo) * C + ch * 8, v);
         store8(out + m * C + ch * 8, v);
@@ -1181,6 +1319,7 @@ extern "C" int istvt_pool_add_fwd(const void* x, const float* bnx, const void* s
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long Mo = (long)Fr * Ho * Wo;
+    if (Mo * (C / 8) + 65536L * 256 > 0x7fffffffL) return ISTVT_ERR_SHAPE;      // 32-bit item index (+ one grid stride)
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_add_fwd_kernel<T>), dim3(ew_grid(Mo * (C / 8))), dim3(256), 0,
                                              stream, (const T*)x, bnx, (const T*)skip, bns, (T*)out, argmax, Mo,
                                              H, W, C, Ho, Wo));
@@ -1198,6 +1337,7 @@ extern "C" int istvt_pool_bwd(const void* dout, const uint8_t* argmax, void* dz,
     static const long cap = istvt_tune("ISTVT_POOLB_BLOCKS", 2048);
     long blocks = (nquads * (C / 8) + 255) / 256;
     if (blocks > cap) blocks = cap;
+    if (nquads + blocks * 256 > 0x7fffffffL) return ISTVT_ERR_SHAPE;            // 32-bit quad index (+ one grid stride)
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, stream,
                                              (const T*)dout, argmax, (T*)dz, nquads, H, W, C, Ho, Wo, (const T*)u, bnp,
                                              st_s1, st_s2));
@@ -1208,6 +1348,7 @@ extern "C" int istvt_subsample2(const void* in, void* out, int Fr, int H, int W,
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long Mo = (long)Fr * Ho * Wo;
+    if (Mo * (C / 8) + 65536L * 256 > 0x7fffffffL) return ISTVT_ERR_SHAPE;      // 32-bit item index (+ one grid stride)
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((subsample2_kernel<T>), dim3(ew_grid(Mo * (C / 8))), dim3(256), 0, stream,
                                              (const T*)in, (T*)out, Mo, H, W, C, Ho, Wo));
     return istvt_check_launch();

@@ -673,6 +673,8 @@ def all_checks():  # noqa: F811
     for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
         out.append(('stem_dwconv_%s' % tag, lambda dt=dt: dwconv_check(dt)))
         out.append(('stem_dwconv_c728_%s' % tag, lambda dt=dt: dwconv_check(dt, 2, 14, 14, 728)))
+        # more tiles than workgroups: the weight gradient's tile loop and its next-tile prefetch run several rounds
+        out.append(('stem_dwconv_many_tiles_%s' % tag, lambda dt=dt: dwconv_check(dt, 40, 61, 45, 64)))
         out.append(('stem_bn_%s' % tag, lambda dt=dt: bn_check(dt)))
         out.append(('stem_bn_c32_%s' % tag, lambda dt=dt: bn_check(dt, 20000, 32)))
         out.append(('stem_pool_%s' % tag, lambda dt=dt: pool_check(dt)))

@@ -40,6 +40,27 @@ for H, C in ((109, 64), (109, 128), (55, 256), (28, 728)):
     print('bn stats+finalize  H=%3d C=%3d  %7.1f us  %6.0f GB/s' % (H, C, t * 1e6, M * C * 2 / t / 1e9), flush=True)
     t = timeit(lambda: S.bn_backward(x, x, bn, g, M, C))
     print('bn bwd stats+apply H=%3d C=%3d  %7.1f us  %6.0f GB/s' % (H, C, t * 1e6, 5 * M * C * 2 / t / 1e9), flush=True)
+# MaxPool2d(3,2,1) + both BatchNorm applies + skip add, and its backward with the BatchNorm-backward sums (the three
+# stride-2 blocks of the entry flow: 109 -> 55 at 128 channels, 55 -> 28 at 256, 28 -> 14 at 728)
+L = _lib.lib()
+for H, C in ((109, 128), (55, 256), (28, 728)):
+    Ho = (H - 1) // 2 + 1
+    M, Ms = Fr * H * H, Fr * Ho * Ho
+    x = rnd(M, C); sk = rnd(Ms, C); out = torch.empty(Ms, C, device='cuda', dtype=dt)
+    amax = torch.empty(Ms, C, device='cuda', dtype=torch.uint8)
+    bnx = S.BNState(C, 'cuda'); bnx.pack.normal_(); bns = S.BNState(C, 'cuda'); bns.pack.normal_()
+    st0 = torch.cuda.current_stream().cuda_stream
+    def pf():
+        _lib.check(L.istvt_pool_add_fwd(x.data_ptr(), bnx.ptr(), sk.data_ptr(), bns.ptr(), out.data_ptr(), amax.data_ptr(),
+                                        Fr, H, H, C, ops._DT[dt], st0), 'pool_add_fwd')
+    t = timeit(pf)
+    print('pool_add_fwd       H=%3d C=%3d  %7.1f us  %6.0f GB/s' % (H, C, t * 1e6, (M * C * 2 + Ms * C * 5) / t / 1e9), flush=True)
+    dz = torch.empty(M, C, device='cuda', dtype=dt); st = S.new_stats(C, 'cuda')
+    def pb():
+        _lib.check(L.istvt_pool_bwd(out.data_ptr(), amax.data_ptr(), dz.data_ptr(), Fr, H, H, C, x.data_ptr(), bnx.ptr(),
+                                    st[0, 0].data_ptr(), st[0, 1].data_ptr(), ops._DT[dt], st0), 'pool_bwd')
+    t = timeit(pb)
+    print('pool_bwd + sums    H=%3d C=%3d  %7.1f us  %6.0f GB/s' % (H, C, t * 1e6, (2 * M * C * 2 + Ms * C * 3) / t / 1e9), flush=True)
 M, D = 56736, 728
 x = rnd(M, D); g = torch.ones(D, device='cuda'); b = torch.zeros(D, device='cuda')
 t = timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-5))
