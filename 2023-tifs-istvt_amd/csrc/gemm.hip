@@ -450,20 +450,26 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 return istvt_check_launch();
             }
             const dim3 grid(pick_grid(tiles, 256));
+            // K % 64 in 1..32 (728, 2912): the last K tile of every output tile runs half its MFMAs (gemm256q.h, KHALF)
+            static const bool khalf_on = istvt_tune("ISTVT_GEMM_KHALF", 1) != 0;
+            const bool kh = khalf_on && K > 64 && (K & 63) != 0 && (K & 63) <= 32;
+#define QL(...) do { if (kh) hipLaunchKernelGGL((gemm256q_kernel<__VA_ARGS__, true>), grid, block, 0, stream, a); \
+                     else hipLaunchKernelGGL((gemm256q_kernel<__VA_ARGS__, false>), grid, block, 0, stream, a); } while (0)
             if (col_sum && col_sumsq) { // fused column statistics: the plain epilogue only (the stem's 1x1 convolutions)
                 if (epi != EPI_NONE || residual) return ISTVT_ERR_SHAPE;
-                hipLaunchKernelGGL((gemm256q_kernel<0, false, 0, 256, 1>), grid, block, 0, stream, a);
+                QL(0, false, 0, 256, 1);
                 return istvt_check_launch();
             }
             if (col_sum) {              // fused column sums of the output: the GELU-backward epilogue (the hidden layer's bias gradient)
                 if (epi != EPI_GELU_BWD) return ISTVT_ERR_SHAPE;
-                hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, 0, 256, 2>), grid, block, 0, stream, a);
+                QL(EPI_GELU_BWD, false, 0, 256, 2);
                 return istvt_check_launch();
             }
-            if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false>), grid, block, 0, stream, a);
-            else if (epi == EPI_GELU_BWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false>), grid, block, 0, stream, a);
-            else if (residual) hipLaunchKernelGGL((gemm256q_kernel<0, true>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((gemm256q_kernel<0, false>), grid, block, 0, stream, a);
+            if (epi == EPI_GELU_FWD) QL(EPI_GELU_FWD, false, 0, 256, 0);
+            else if (epi == EPI_GELU_BWD) QL(EPI_GELU_BWD, false, 0, 256, 0);
+            else if (residual) QL(0, true, 0, 256, 0);
+            else QL(0, false, 0, 256, 0);
+#undef QL
             return istvt_check_launch();
         }
         if (a_sel) return ISTVT_ERR_SHAPE;          // only the persistent NT kernel selects its A plane by column tile

@@ -40,6 +40,7 @@
 //   * vmcnt: phase 2kt+1 needs AH = 4kt+3, issued by then <= 4kt+7: 8 pieces may stay in flight; phase 2kt+2 needs
 //     units <= 4kt+6, issued <= 4kt+9: 6 pieces.  Fewer exist only at the end of the stream.
 #pragma once
+#include <type_traits>
 
 // -DISTVT_Q_ORDER=1: the round-1 order inside a load slot (fragment reads, then the DMA issue) for A/B runs
 #ifndef ISTVT_Q_ORDER
@@ -124,7 +125,11 @@ __device__ __forceinline__ void slot_barrier() {
 // (N = 2912 is 12 column tiles and a workgroup changes column with almost every tile, so it flushes per tile: float
 // atomics straight into the 2912 addresses of the gradient made every launch 60 us longer -- same-address contention --,
 // 32 replicas + istvt_stats_reduce_add do not.)
-template <int EPI, bool SIDE, int DBG = 0, int TM = 256, int STATS = 0>
+// KHALF (host: K % 64 in 1..32 and more than one K tile -- the model's 728 and 2912): the second 32-deep MFMA step of an
+// output tile's LAST K tile multiplies zero padding only; that tile runs half its MFMAs and fragment reads (ktile1's
+// HALF): 1/24 of the MFMAs at K = 728.  A template parameter, not a run-time branch: two copies of the last K tile behind
+// a branch made the register allocator spill (300 bytes of scratch per lane).
+template <int EPI, bool SIDE, int DBG = 0, int TM = 256, int STATS = 0, bool KHALF = false>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     static_assert(TM == 256 || TM == 224, "row tile");
     static_assert(STATS != 1 || (EPI == 0 && !SIDE && TM == 256), "BatchNorm statistics ride in the plain epilogue only");
@@ -348,8 +353,10 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             st1[j] = xsum_lanes_8_16_32(st1[j]);
             if constexpr (STATS == 1) st2[j] = xsum_lanes_8_16_32(st2[j]);
         }
-        const int col = st_bn0 + wn * 64 + (lane & 7) * 8;
-        if ((lane >> 3) == 0 && col < p.N) {
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));        // opaque per call: the lane predicate / column are not kept live (or spilled) across tiles
+        const int col = st_bn0 + wn * 64 + (lane_s & 7) * 8;
+        if ((lane_s >> 3) == 0 && col < p.N) {
             if constexpr (STATS == 1) {
                 const long rep = (long)(blockIdx.x % ISTVT_STAT_REPLICAS) * 2 * p.N;
 #pragma unroll
@@ -435,7 +442,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             if (ti > 0) gap_c += k0_c - t_ep_end;
         }
 
-        auto ktile1 = [&](const bool first, const bool last) {
+        auto ktile1 = [&](const bool first, const bool last, auto half_tag) {
+            constexpr bool HALF = decltype(half_tag)::value;
             const char* ubase = smem + (KT & 1) * 4 * QU_BYTES;
             const char* ua_lo = ubase;
             const char* ua_hi = ubase + 3 * QU_BYTES;
@@ -456,7 +464,9 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             if (first && p.bias) {
                 // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped); it is
                 // older than the 8 pieces of this K tile's two load slots, so the wait that closes L_B covers it
-                const int col = min(bn0 + wn * 64 + lane, p.N - 1);
+                int lane_b = lane;
+                asm volatile("" : "+v"(lane_b));    // opaque per tile, as in stats_flush
+                const int col = min(bn0 + wn * 64 + lane_b, p.N - 1);
                 dma4_lds(__builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.bias), 0, p.N * 4, RSRC_FLAGS),
                          (unsigned)(__SIZE_TYPE__)(lds_void*)slab, (unsigned)(col * 4), 0);
             }
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 bq[t][0] = rd(ub + la_b[0] + t * 2048, t);
-                bq[t][1] = rd(ub + la_b[1] + t * 2048, t + 4);
+                if constexpr (!HALF) bq[t][1] = rd(ub + la_b[1] + t * 2048, t + 4);
             }
             stamp(2, false);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // AH(k) landed
@@ -478,9 +488,22 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 #define QSTEP(i)                                                                                                        \
             if ((i) + 2 < 8) af[((i) + 2) & 3][((i) + 2) >> 2] = rd(ua_lo + la_a[((i) + 2) >> 2] + (((i) + 2) & 3) * 2048, 10 + (i)); \
             mma4((i) & 3, (i) & 3, (i) >> 2);
+#define QSTEPH(i)                                                                                                       \
+            if ((i) + 2 < 4) af[(i) + 2][0] = rd(ua_lo + la_a[0] + ((i) + 2) * 2048, 10 + (i));                           \
+            mma4((i), (i), 0);
+            if constexpr (HALF) {
+                QSTEPH(0) QSTEPH(1) QSTEPH(2) QSTEPH(3)
+                if (!(DBG & 6)) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                }
+            } else {
             QSTEP(0) QSTEP(1) QSTEP(2) QSTEP(3) QSTEP(4) QSTEP(5) QSTEP(6) QSTEP(7)
+            }
 #undef QSTEP
-            if (!(DBG & 6)) {
+#undef QSTEPH
+            if (!HALF && !(DBG & 6)) {
                 // the order the scheduler is to emit: 3 reads, then 4 MFMAs + 1 read five times, then the MFMAs left
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             for (int t = 0; t < 4; ++t) {
                 if (t >= NB) continue;
                 af[t][0] = rd(ua_hi + la_h[0] + t * 2048, 20 + t);
-                af[t][1] = rd(ua_hi + la_h[1] + t * 2048, 24 + t);
+                if constexpr (!HALF) af[t][1] = rd(ua_hi + la_h[1] + t * 2048, 24 + t);
             }
             if (last) { lane_offsets(); if (HAS_SIDE) fetch_side(0); }
             stamp(8, false);
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             stamp(10, false);
             // ---- C_B: AH x B
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh)
+            for (int kh = 0; kh < (HALF ? 1 : 2); ++kh)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (t >= NB) continue;
@@ -576,7 +599,9 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             if (first && p.bias) {
                 // this wavefront's 64 bias values -> slab[0..63] by one 4-byte-per-lane LDS-DMA (columns past N clamped);
                 // issued BEFORE this slot's units, so that the wait at the end of phase B covers it
-                const int col = min(bn0 + wn * 64 + lane, p.N - 1);
+                int lane_b = lane;
+                asm volatile("" : "+v"(lane_b));    // opaque per tile, as in stats_flush
+                const int col = min(bn0 + wn * 64 + lane_b, p.N - 1);
                 dma4_lds(__builtin_amdgcn_make_buffer_rsrc(uni_ptr(p.bias), 0, p.N * 4, RSRC_FLAGS),
                          (unsigned)(__SIZE_TYPE__)(lds_void*)slab, (unsigned)(col * 4), 0);
             }
@@ -633,11 +658,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             U0 += 4;
         };
 #if ISTVT_Q_SCHED == 1
-#define ktile ktile1
+#define ktile(f, l) ktile1(f, l, std::false_type{})
 #else
-#define ktile ktile0
+#define ktile(f, l) ktile0(f, l)
 #endif
-        ktile(true, nkt == 1);
+        ktile(true, KHALF ? false : nkt == 1);      // (KHALF: the host guarantees more than one K tile)
         if (p.bias) {
             // the bias DMA was issued in phase A of the first K tile, before units U0-4+6..9: phase B's wait covered it
 #pragma unroll
@@ -648,6 +673,10 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             }
         }
         for (int s = 1; s < nkt - 1; ++s) ktile(false, false);
+#if ISTVT_Q_SCHED == 1
+        if constexpr (KHALF) ktile1(false, true, std::true_type{});
+        else
+#endif
         if (nkt > 1) ktile(false, true);
         if constexpr ((DBG & 1280) != 0) {
             const unsigned long long k1_c = __builtin_amdgcn_s_memtime(), k1_r = __builtin_amdgcn_s_memrealtime();

@@ -307,7 +307,10 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
             use224 = tm_env == 224 or (tm_env == -1 and -(-t224 // cus) * 224 < -(-t256 // cus) * 256)
             if stats:                   # 1: BatchNorm statistics, 2: column sums in the epilogue (always the 256-row tile)
                 use224 = False
-            return 'gemm256q_kernel<%d, %s, 0, %d, %d>' % (epi, side, 224 if use224 else 256, stats)
+            # KHALF: K % 64 in 1..32 -> the last K tile of every output tile runs half its MFMAs (256-row tile only)
+            khalf = (not use224) and K > 64 and 0 < (K & 63) <= 32
+            return 'gemm256q_kernel<%d, %s, 0, %d, %d, %s>' % (epi, side, 224 if use224 else 256, stats,
+                                                               'true' if khalf else 'false')
         t_ok = (not a_kc and out_mode == 3 and bias is None and residual is None and epi == 0 and K * lda * 2 < 0x7fffffff
                 and K * ldb * 2 < 0x7fffffff)
         if t_ok:
