@@ -129,6 +129,14 @@ __device__ __forceinline__ void slot_barrier() {
 // output tile's LAST K tile multiplies zero padding only; that tile runs half its MFMAs and fragment reads (ktile1's
 // HALF): 1/24 of the MFMAs at K = 728.  A template parameter, not a run-time branch: two copies of the last K tile behind
 // a branch made the register allocator spill (300 bytes of scratch per lane).
+// Cache-policy bits of the output stores: 2 = nt (non-temporal: the output lines stream through L2 instead of displacing
+// the operand panels every tile of a column re-reads).  Measured at the model's shapes, same box (tools/gemm_bench.py):
+// N=2912 K=728 plain 277..283 -> 269 us, GELU 336 -> 318, N=1536 131 -> 125, bias+residual N=1024 112 -> 97; K=512 N=728
+// 51 -> 53; the train step 52.4..52.7 -> 52.1 ms (the consumers of the outputs lose nothing measurable).  sc1 (16) alone
+// +1..3 %, nt + sc1 as nt.  The stem's statistics launches (64..728-column outputs) measured 3 % slower with nt: they keep 0.
+#ifndef ISTVT_Q_STORE_AUX
+#define ISTVT_Q_STORE_AUX (STATS == 1 ? 0 : 2)
+#endif
 template <int EPI, bool SIDE, int DBG = 0, int TM = 256, int STATS = 0, bool KHALF = false>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     static_assert(TM == 256 || TM == 224, "row tile");
@@ -697,9 +705,33 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int re = lane_e & 15, ge = lane_e >> 4, rowe = lane_e >> 3, l7 = lane_e & 7;
+        // The slab round trip of pass p + 1 (four 16-byte writes, four reads back as output rows) is issued BEFORE pass p is
+        // converted and stored: a wavefront's LDS operations execute in order, so the reads of pass p are older than the
+        // writes of pass p + 1 that overwrite the slab, and each pass's LDS latency (twice per pass when the reads of its
+        // second half followed the arithmetic of its first) hides under the previous pass's arithmetic and stores.
+        constexpr int NPASS = TM == 224 ? 7 : 8;        // the AH unit holds three row tiles per wavefront at 224 rows
+        f32x4 xlo[2][2], xhi[2][2];
+        auto slab_trip = [&](const int pass) {
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            if (TM == 224 && pass == 7) continue;       // the AH unit holds three row tiles per wavefront
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(slab + re * 64 + (((nt * 4 + ge) ^ re) << 2)) = acc[pass][nt];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + rowe;
+                xlo[pass & 1][it] = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7) ^ row) << 2));
+                xhi[pass & 1][it] = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7 + 1) ^ row) << 2));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        };
+        slab_trip(0);
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (pass + 1 < NPASS) slab_trip(pass + 1);
             if (LATE_Q3 && pass == 2) fetch_side(2);
             if (LATE_Q3 && pass == 4) fetch_side(3);
             if (HAS_SIDE && (pass & 1) == 0) {
@@ -711,19 +743,11 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 else
                     asm volatile("s_waitcnt vmcnt(8)" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)::"memory");
             }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<f32x4*>(slab + re * 64 + (((nt * 4 + ge) ^ re) << 2)) = acc[pass][nt];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
             u32x4 held[2], held2[2];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const int row = it * 8 + rowe;
                 const int rb = QRB(pass * 2 + it);
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7) ^ row) << 2));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * 64 + (((2 * l7 + 1) ^ row) << 2));
+                const f32x4 lo = xlo[pass & 1][it], hi = xhi[pass & 1][it];
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] = lo[j] * alpha; v[4 + j] = hi[j] * alpha; }
@@ -755,7 +779,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                     }
                 }
                 held[it] = __builtin_bit_cast(u32x4, o);
-                __builtin_amdgcn_raw_buffer_store_b128(held[it], c_rs, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(held[it], c_rs, voff, soff, ISTVT_Q_STORE_AUX);
                 if (EPI == EPI_GELU_FWD) {
                     bf16x8 o2;
 #pragma unroll
@@ -764,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                         o2[j] = (bf16_t)gv.x; o2[j + 1] = (bf16_t)gv.y;
                     }
                     held2[it] = __builtin_bit_cast(u32x4, o2);
-                    __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, ISTVT_Q_STORE_AUX);
                 }
             }
             // STORE-DATA HAZARD, see gemm_shared.h
@@ -772,9 +796,6 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1]), "+v"(held2[0]), "+v"(held2[1])::"memory");
             else
                 asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1])::"memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         }
 #undef QRB
         if constexpr ((DBG & 1280) != 0) {
