@@ -134,6 +134,9 @@ __device__ __forceinline__ void slot_barrier() {
 // N=2912 K=728 plain 277..283 -> 269 us, GELU 336 -> 318, N=1536 131 -> 125, bias+residual N=1024 112 -> 97; K=512 N=728
 // 51 -> 53; the train step 52.4..52.7 -> 52.1 ms (the consumers of the outputs lose nothing measurable).  sc1 (16) alone
 // +1..3 %, nt + sc1 as nt.  The stem's statistics launches (64..728-column outputs) measured 3 % slower with nt: they keep 0.
+#ifndef ISTVT_Q_SIDE_NT
+#define ISTVT_Q_SIDE_NT 0
+#endif
 #ifndef ISTVT_Q_STORE_AUX
 #define ISTVT_Q_STORE_AUX (STATS == 1 ? 0 : 2)
 #endif
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             for (int q = 0; q < 4; ++q) {
                 const int idx = quarter * 4 + q;
                 const int rb = QRB(idx);
-                sv[idx] = buf_load16(side_rs(), (rb < rows_left && !(TM == 224 && idx >= 14)) ? s_off : OOB, rb * lds_ * 2);
+                sv[idx] = buf_load16<ISTVT_Q_SIDE_NT != 0>(side_rs(), (rb < rows_left && !(TM == 224 && idx >= 14)) ? s_off : OOB, rb * lds_ * 2);
             }
         };
         f32x4 acc[8][4];

@@ -66,8 +66,13 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& p, int m, int n, 
 // first use of any loaded value, which drains the ring once per tile.  Lanes outside the matrix use the buffer
 // instructions' range check (offset >= num_records: loads return 0, stores are dropped) instead of branches, so every
 // lane issues the same number of operations.
+template <bool NT = false>
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
     u32x4 v;
+    if constexpr (NT) {          // read-once data (see the s_nop note below)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+        return v;
+    }
     // s_nop 4: the compiler does not know this statement is a VMEM instruction, so it does not pad the 5 wait states a
     // VMEM read of an SGPR needs after a VALU wrote it (v_readfirstlane of a descriptor word, v_readlane of a spilled
     // scalar offset): without them the load went out with the PREVIOUS value of the scalar offset (seen on gfx950).

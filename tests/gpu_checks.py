@@ -1002,6 +1002,13 @@ def all_checks():  # noqa: F811
     out.append(('gemm_production_fwd_bias_res_N728_K2912', lambda: gemm_production('fwd_bias_res', 728, 2912)))
     out.append(('gemm_production_fwd_bias_res_N728_K512', lambda: gemm_production('fwd_bias_res', 728, 512)))
     out.append(('gemm_production_fwd_gelu_N2912_K728', lambda: gemm_production('fwd_gelu', 2912, 728)))
+    # the last K tile of an output tile runs half its MFMAs when K % 64 is 1..32 (gemm256q.h KHALF): both sides of the rule,
+    # two and three K tiles, every epilogue
+    for K in (72, 96, 97, 160, 168):
+        out.append(('gemm_khalf_edge_fwd_K%d' % K, lambda K=K: gemm_production('fwd', 512, K, M=3000, nsample=3000)))
+        out.append(('gemm_khalf_edge_bias_res_K%d' % K, lambda K=K: gemm_production('fwd_bias_res', 512, K, M=3000, nsample=3000)))
+    out.append(('gemm_khalf_edge_gelu_K96', lambda: gemm_production('fwd_gelu', 512, 96, M=3000, nsample=3000)))
+    out.append(('gemm_khalf_edge_dgrad_gelu_K96', lambda: gemm_production('dgrad_gelu', 96, 512, M=3000, nsample=3000)))
     out.append(('gemm_production_dgrad_gelu_N728_K2912', lambda: gemm_production('dgrad_gelu', 728, 2912)))
     out.append(('attn_spatial_production_BF2304', attn_spatial_production))
     out.append(('attn_spatial_production_P362', lambda: attn_spatial_production(448, 362, 8, 64, 16)))
