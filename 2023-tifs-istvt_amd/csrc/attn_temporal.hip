@@ -536,6 +536,7 @@ extern "C" int istvt_attn_temporal_fwd(const void* qk, long ldqk, const void* v,
     static const int use_mfma = istvt_tune("ISTVT_TATTN_MFMA", 1);
     if (use_mfma && dtype == DT_BF16 && F <= 32 && (dh == 64 || dh == 32)) {     // one wavefront per (b, p, h), MFMA tiles
         const long nprob = (long)B * P * heads;
+        if (nprob > 0x3fffffffL) return ISTVT_ERR_SHAPE;      // 32-bit problem index in the kernels
         dim3 grid((unsigned)((nprob + 3) / 4)), block(256);
 #define TATTN_F(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_fwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (bf16_t*)out, B, F, P, heads, scale, ldqk, ldv, ldo, diff)
         if (dh == 64) { if (F <= 16) TATTN_F(64, 1); else TATTN_F(64, 2); }
@@ -560,6 +561,7 @@ extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v,
     static const int mfma_bwd_min = istvt_tune("ISTVT_TATTN_MFMA_BWD_MINF", 1);
     if (use_mfma && dtype == DT_BF16 && F >= mfma_bwd_min && F <= 32 && (dh == 64 || dh == 32)) {
         const long nprob = (long)B * P * heads;
+        if (nprob > 0x3fffffffL) return ISTVT_ERR_SHAPE;      // 32-bit problem index in the kernel (+ one grid stride)
         long nwg = (nprob + 3) / 4;
         const long resident = 256L * (F <= 16 ? 4 : 2);      // workgroups per CU by registers (105 / 213 VGPRs at dh 64)
         if (nwg > resident) nwg = resident;                   // wavefronts loop over problems

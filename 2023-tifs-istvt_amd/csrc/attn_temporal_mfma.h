@@ -174,11 +174,15 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
                                                              float scale, long ldqk, long ldv, long ldo, int diff) {
     constexpr int LDI = DH + tmf::IPAD, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][16 * NTL * LDI];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
-    const long prob = (long)blockIdx.x * 4 + wave;
-    if (prob >= (long)B * P * heads) return;              // no workgroup-level synchronisation below
-    const int h = (int)(prob % heads);
-    const long bp = prob / heads, b = bp / P, p = bp % P;
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    // the wavefront's problem -> (clip, position, head) on the SCALAR unit, in 32 bits (the host checks the count): from the
+    // lane-valued threadIdx.x >> 6 in `long` these were three 64-bit divisions per lane on the vector ALU
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned prob = blockIdx.x * 4u + (unsigned)wave;
+    if (prob >= (unsigned)B * P * heads) return;          // no workgroup-level synchronisation below
+    const unsigned bpu = prob / (unsigned)heads, bu = bpu / (unsigned)P;
+    const int h = (int)(prob - bpu * heads);
+    const long b = bu, p = bpu - bu * (unsigned)P;
     const int inner = heads * DH;
     const long row0 = b * F * P + p;
     const long sq = (long)P * ldqk, sv = (long)P * ldv, so = (long)P * ldo;
@@ -261,9 +265,12 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     constexpr int IMG = 16 * NTL * LDI;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4][3 * IMG];
     __shared__ __attribute__((aligned(16))) float stat[4][3][16 * NTL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
-    const long total = (long)B * P * heads, nwaves = (long)gridDim.x * 4;
-    long prob = (long)blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    // problem arithmetic on the scalar unit, in 32 bits (see the forward kernel): six 64-bit vector divisions per problem
+    // otherwise, in a kernel that is bound by its vector issue
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned total = (unsigned)B * P * heads, nwaves = gridDim.x * 4u;
+    unsigned prob = blockIdx.x * 4u + (unsigned)wave;
     if (prob >= total) return;                            // no workgroup-level synchronisation below
     const int inner = heads * DH;
     const long sq = (long)P * ldqk, sv = (long)P * ldv, so = (long)P * ldo;
@@ -277,9 +284,10 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     // in registers -- one problem per wavefront left five wavefronts per SIMD each idling through its own latency.
     constexpr int VPR = DH / 8, RPI = 64 / VPR, NIT = 16 * NTL / RPI;
     bf16x8 nq[NIT], nk[NIT], nd[NIT], nv[NTL][KS];
-    auto fetch = [&](long pr) {
-        const int h = (int)(pr % heads);
-        const long bp = pr / heads, b = bp / P, pp = bp % P;
+    auto fetch = [&](unsigned pr) {
+        const unsigned bpu = pr / (unsigned)heads, bu = bpu / (unsigned)P;
+        const int h = (int)(pr - bpu * heads);
+        const long b = bu, pp = bpu - bu * (unsigned)P;
         const long row0 = b * F * P + pp;
         const bf16_t* qp = qk + row0 * ldqk + h * DH;
         const bf16_t* kp = qp + inner;
@@ -299,8 +307,9 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
     };
     fetch(prob);
     for (; prob < total; prob += nwaves) {
-    const int h = (int)(prob % heads);
-    const long bp = prob / heads, b = bp / P, p = bp % P;
+    const unsigned bpu = prob / (unsigned)heads, bu = bpu / (unsigned)P;
+    const int h = (int)(prob - bpu * heads);
+    const long b = bu, p = bpu - bu * (unsigned)P;
     const long row0 = b * F * P + p;
     bf16_t* dqp = dqk + row0 * ldqk + h * DH;
     bf16_t* dkp = dqp + inner;

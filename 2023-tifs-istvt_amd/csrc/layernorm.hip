@@ -109,12 +109,14 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
                                                           float* __restrict__ rstd_out, int Bn, int F, int P, int D,
                                                           float eps, long ldx, long ldy, long ldd) {
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long nwaves = (long)gridDim.x * 4;
+    // position arithmetic on the scalar unit, in 32 bits (the launcher checks B * P): as `long` from the lane-valued
+    // threadIdx.x >> 6 every position cost four 64-bit vector divisions
+    const unsigned wave = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned nwaves = gridDim.x * 4u;
     float gm[LN_MAXCH][8], bt[LN_MAXCH][8];
     ln_row_load<float>(gamma, D, lane, gm);
     ln_row_load<float>(beta, D, lane, bt);
-    const long npos = (long)Bn * P;
+    const unsigned npos = (unsigned)Bn * (unsigned)P, Pu = (unsigned)P;
     // the next row of the walk (next frame, or frame 0 of this wavefront's next position) is requested before the
     // current one is reduced (see ln_fwd_kernel)
     typename Mma<T>::frag nxt[LN_MAXCH];
@@ -125,9 +127,10 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
             if (e < D) nxt[c] = frag_load(x + m * ldx + e);
         }
     };
-    if (wave < npos) fetch(((wave / P) * F) * P + wave % P);
-    for (long w = wave; w < npos; w += nwaves) {
-        const long b = w / P, pp = w % P;
+    auto first_row = [&](unsigned w) { const unsigned b = w / Pu; return ((long)b * F) * P + (w - b * Pu); };
+    if (wave < npos) fetch(first_row(wave));
+    for (unsigned w = wave; w < npos; w += nwaves) {
+        const long b = w / Pu, pp = w - (w / Pu) * Pu;
         float prev[LN_MAXCH][8];
         for (int f = 0; f < F; ++f) {
             const long m = (b * F + f) * P + pp;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_fwd_diff_kernel(const T* __restrict__ 
                 for (int i = 0; i < 8; ++i) v[c][i] = e < D ? Mma<T>::get(nxt[c], i) : 0.f;
             }
             if (f + 1 < F) fetch(m + P);
-            else if (w + nwaves < npos) fetch((((w + nwaves) / P) * F) * P + (w + nwaves) % P);
+            else if (w + nwaves < npos) fetch(first_row(w + nwaves));
             float mean, rstd;
             ln_stats(v, D, lane, eps, mean, rstd);
 #pragma unroll
@@ -477,6 +480,7 @@ extern "C" int istvt_layernorm_fwd_diff(const void* x, long ldx, const float* ga
                                         float eps, int dtype, hipStream_t stream) {
     if (D % 8 != 0 || D > LN_MAXCH * 512 || B <= 0 || F <= 0 || P <= 0) return ISTVT_ERR_SHAPE;
     if (ldx < D || ldy < D || ldd < D || ldx % 8 || ldy % 8 || ldd % 8) return ISTVT_ERR_SHAPE;
+    if ((long)B * P > 0x3fffffffL) return ISTVT_ERR_SHAPE;            // 32-bit position index in the kernel
     DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_fwd_diff_kernel<T>), dim3(ln_grid((long)B * P)), dim3(256), 0, stream,
                                              (const T*)x, gamma, beta, (T*)y, (T*)diff, mean, rstd, B, F, P, D, eps, ldx,
                                              ldy, ldd));

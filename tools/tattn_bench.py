@@ -13,6 +13,7 @@ from istvt_amd import ops  # noqa: E402
 
 dt = torch.bfloat16
 B, P, heads, dh = 32, 197, 8, 64
+DIFF = int(os.environ.get("TB_DIFF", 2))          # 2: pre-differenced operands (what the model runs since round 4), 1: differenced scores
 
 
 def timeit(fn, reps=10):
@@ -33,7 +34,7 @@ for F in (9, 17):
     qk, v = qkv[:, :1024], qkv[:, 1024:]
     do = ops.empty_rows(M, 512, dt, 'cuda')
     do.copy_(torch.randn(M, 512, device='cuda'))
-    t = timeit(lambda: ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh, diff=True))
+    t = timeit(lambda: ops.attn_temporal_fwd(qk, v, B, F, P, heads, dh, diff=DIFF))
     print('F=%2d fwd %7.1f us  %5.2f TB/s' % (F, t * 1e6, M * 2048 * 2 / t / 1e12), flush=True)
-    t = timeit(lambda: ops.attn_temporal_bwd(qk, v, do, B, F, P, heads, dh, diff=True, packed=True))
+    t = timeit(lambda: ops.attn_temporal_bwd(qk, v, do, B, F, P, heads, dh, diff=DIFF, packed=True))
     print('F=%2d bwd %7.1f us  %5.2f TB/s' % (F, t * 1e6, M * 3584 * 2 / t / 1e12), flush=True)
