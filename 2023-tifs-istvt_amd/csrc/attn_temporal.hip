@@ -563,7 +563,7 @@ extern "C" int istvt_attn_temporal_bwd(const void* qk, long ldqk, const void* v,
         const long nprob = (long)B * P * heads;
         if (nprob > 0x3fffffffL) return ISTVT_ERR_SHAPE;      // 32-bit problem index in the kernel (+ one grid stride)
         long nwg = (nprob + 3) / 4;
-        const long resident = 256L * (F <= 16 ? 4 : 2);      // workgroups per CU by registers (105 / 213 VGPRs at dh 64)
+        const long resident = 256L * (F <= 16 ? ISTVT_TB_WPE : 2);      // workgroups per CU by registers (105 / 213 VGPRs at dh 64)
         if (nwg > resident) nwg = resident;                   // wavefronts loop over problems
         dim3 grid((unsigned)nwg), block(256);
 #define TATTN_B(DHV, NTLV) hipLaunchKernelGGL((tattn_mfma_bwd_kernel<DHV, NTLV>), grid, block, 0, stream, (const bf16_t*)qk, (const bf16_t*)v, (const bf16_t*)dout, (bf16_t*)dqk, (bf16_t*)dv, B, F, P, heads, scale, ldqk, ldv, ldo, diff)

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
         tmf::diff_lanes<NTL, NTL>(s, r);
         tmf::diff_rows<NTL, NTL>(s, lane);
     }
+    float inv_u[NTL];
 #pragma unroll
     for (int u = 0; u < NTL; ++u) {
+        inv_u[u] = 0.f;
         if (16 * u >= F) break;
         // softmax over keys: lane owns query r, keys 16t + 4g + j
         float mx = -INFINITY;
@@ -242,22 +244,50 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
                 sum += pv;
             }
         sum = tmf::group_sum(sum);
-        const float inv = 1.0f / sum;
-        const int q = 16 * u + r;
+        inv_u[u] = 1.0f / sum;
+    }
+    // O^T = V^T P^T by 16-column blocks.  The output rows leave through the V image (column block 16 dt is dead once every
+    // query tile's product has read it) and are stored as whole 16-byte chunks, 64 per instruction: F = 9, DH = 64 is two
+    // stores (1 KiB + 128 B) instead of four 8-byte-per-lane stores with 36 lanes active (see the backward kernel).
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            f32x4 o = f32x4{0, 0, 0, 0};
-            tmf::mma_frames<NTL>(o, Vimg, LDI, 16 * dt, g, r, s[0][u], s[NTL - 1][u]);
-            if (q < F) {
-                float ov[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
-                store4(op + (long)q * so + 16 * dt + 4 * g, ov);
+    for (int dt = 0; dt < DT; ++dt) {
+        f32x4 o[NTL];
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+            o[u] = f32x4{0, 0, 0, 0};
+            if (16 * u < F) tmf::mma_frames<NTL>(o[u], Vimg, LDI, 16 * dt, g, r, s[0][u], s[NTL - 1][u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+            float ov[4] = {o[u][0] * inv_u[u], o[u][1] * inv_u[u], o[u][2] * inv_u[u], o[u][3] * inv_u[u]};
+            store4(Vimg + (16 * u + r) * LDI + 16 * dt + 4 * g, ov);
+        }
+    }
+    tmf::wave_lds_fence();
+    {
+        constexpr int VPR = DH / 8;
+        const int n1 = F * VPR;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int idx = i0 + lane;
+            if (idx < n1) {
+                const int row = idx / VPR, ch = idx % VPR;
+                *reinterpret_cast<bf16x8*>(op + (long)row * so + ch * 8) = *reinterpret_cast<const bf16x8*>(Vimg + row * LDI + ch * 8);
             }
         }
     }
 }
 
+#ifdef ISTVT_TATTN_NOSTORE          // diagnostic: what do the backward kernel's 8-byte output stores cost?
+#define TB_STORE8(p, v) do { if (scale < -1e30f) *reinterpret_cast<bf16x8*>(p) = (v); } while (0)
+#else
+#define TB_STORE8(p, v) (*reinterpret_cast<bf16x8*>(p) = (v))
+#endif
+#ifndef ISTVT_TB_WPE
+#define ISTVT_TB_WPE 4
+#endif
 template <int DH, int NTL>
-__global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTL == 1 ? ISTVT_TB_WPE : 2, NTL == 1 ? ISTVT_TB_WPE : 2)))
+void tattn_mfma_bwd_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ v,
                                                              const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqk,
                                                              bf16_t* __restrict__ dv, int B, int F, int P, int heads,
                                                              float scale, long ldqk, long ldv, long ldo, int diff) {
@@ -408,13 +438,12 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
             // diff == 2: q', k' arrived differenced (K' is what the images hold), dQ' = dS' K' is the gradient w.r.t. q';
             // the caller wants it w.r.t. the un-differenced projection: dQ = D^T dQ' along the frames (= the lanes here)
             if (diff == 2) tmf::adj_lanes<1, NTL>(dq, r);
+            // Output rows leave through the images (see the end of the problem): this column block of K is dead once
+            // every query tile's product has read it, and part 2 does not read the K image at all
 #pragma unroll
             for (int u = 0; u < NTL; ++u) {
-                const int q = 16 * u + r;
-                if (q < F) {
-                    float o[4] = {dq[0][u][0], dq[0][u][1], dq[0][u][2], dq[0][u][3]};
-                    store4(dqp + (long)q * sq + 16 * dt + 4 * g, o);
-                }
+                float o[4] = {dq[0][u][0], dq[0][u][1], dq[0][u][2], dq[0][u][3]};
+                store4(Kimg + (16 * u + r) * LDI + 16 * dt + 4 * g, o);
             }
         }
     }
@@ -461,28 +490,42 @@ __global__ __launch_bounds__(256) void tattn_mfma_bwd_kernel(const bf16_t* __res
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            f32x4 dkk[1][NTL];
+            f32x4 dkk[1][NTL], dvv[NTL];
 #pragma unroll
             for (int kt = 0; kt < NTL; ++kt) {
                 dkk[0][kt] = f32x4{0, 0, 0, 0};
+                dvv[kt] = f32x4{0, 0, 0, 0};
                 if (16 * kt >= F) continue;
-                f32x4 dvv = f32x4{0, 0, 0, 0};
-                tmf::mma_frames<NTL>(dvv, Dimg, LDI, 16 * dt, g, r, s[0][kt], s[NTL - 1][kt]);
+                tmf::mma_frames<NTL>(dvv[kt], Dimg, LDI, 16 * dt, g, r, s[0][kt], s[NTL - 1][kt]);
                 tmf::mma_frames<NTL>(dkk[0][kt], Qimg, LDI, 16 * dt, g, r, dp[0][kt], dp[NTL - 1][kt]);
-                const int key = 16 * kt + r;
-                if (key < F) {
-                    float bb[4] = {dvv[0], dvv[1], dvv[2], dvv[3]};
-                    store4(dvp + (long)key * sv + 16 * dt + 4 * g, bb);
-                }
             }
             if (diff == 2) tmf::adj_lanes<1, NTL>(dkk, r);         // dK = D^T dK' (see dQ above)
+            // column block 16 dt of the dO and Q images is dead now (every key tile's products have read it): dV and dK
+            // rows take its place
 #pragma unroll
             for (int kt = 0; kt < NTL; ++kt) {
-                const int key = 16 * kt + r;
-                if (key < F) {
-                    float a[4] = {dkk[0][kt][0], dkk[0][kt][1], dkk[0][kt][2], dkk[0][kt][3]};
-                    store4(dkp + (long)key * sq + 16 * dt + 4 * g, a);
-                }
+                float bb[4] = {dvv[kt][0], dvv[kt][1], dvv[kt][2], dvv[kt][3]};
+                float a[4] = {dkk[0][kt][0], dkk[0][kt][1], dkk[0][kt][2], dkk[0][kt][3]};
+                store4(Dimg + (16 * kt + r) * LDI + 16 * dt + 4 * g, bb);
+                store4(Qimg + (16 * kt + r) * LDI + 16 * dt + 4 * g, a);
+            }
+        }
+    }
+    // ---- the three gradients leave as whole 16-byte chunks of their rows: 3 F rows x DH / 8 chunks, 64 per instruction
+    // (F = 9, DH = 64: 4 stores of 1 KiB, 1 KiB, 1 KiB, 384 B).  Straight from the accumulator layout they were 12 stores
+    // of 8 bytes per lane with 36 lanes active (288 B each), and the kernel spent more than half its time on them:
+    // 109.6 us with, 50.2 us without its stores (tools/tattn_bench.py, -DISTVT_TATTN_NOSTORE).
+    tmf::wave_lds_fence();
+    {
+        const int n1 = F * VPR;                            // chunks per matrix; image m: 0 = Q (dK), 1 = K (dQ), 2 = dO (dV)
+        // (a real loop: unrolled, with every LDS read ahead of the first store, it measured 85 -> 105 us at F = 9)
+        for (int i0 = 0; i0 < 3 * n1; i0 += 64) {
+            const int idx = i0 + lane;
+            if (idx < 3 * n1) {
+                const int m = (idx >= n1) + (idx >= 2 * n1), rem = idx - m * n1, row = rem / VPR, ch = rem % VPR;
+                const bf16x8 val = *reinterpret_cast<const bf16x8*>(Qimg + m * IMG + row * LDI + ch * 8);
+                bf16_t* dst = (m == 0 ? dkp : m == 1 ? dqp : dvp) + (long)row * (m == 2 ? sv : sq) + ch * 8;
+                TB_STORE8(dst, val);
             }
         }
     }
