@@ -34,6 +34,11 @@ constexpr int NT = CHUNK / 16;      // 16-row tiles per chunk
 // ds_read_b128 lane group (16 rows x 16 bytes) each touch all 64 banks exactly once.  DH + 8 (144 bytes = 36 banks) put
 // row 7 on top of row 0's first four banks: every transposed read and most row reads were 2-way conflicts (PMC round 2:
 // SQ_LDS_BANK_CONFLICT = 43 % of the LDS cycles of these kernels).  float32 keeps DH + 8 (72 dwords = 8 mod 64).
+#ifdef ISTVT_SATTN_NOSTORE         // diagnostic: what do the backward's 8-byte output stores cost?
+#define SB_STORE4(p, v) do { if (scale < -1e30f) store4(p, v); } while (0)
+#else
+#define SB_STORE4(p, v) store4(p, v)
+#endif
 template <typename T, int DH> struct Pitch { static constexpr int v = DH + (sizeof(T) == 2 ? 16 : 8); };
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -561,7 +566,7 @@ __device__ __forceinline__ void sattn_dq_body(const T* __restrict__ qkv, const T
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             float v[4] = {dq[dt][u][0] * scale, dq[dt][u][1] * scale, dq[dt][u][2] * scale, dq[dt][u][3] * scale};
-            store4(dqp + 16 * dt + 4 * g, v);
+            SB_STORE4(dqp + 16 * dt + 4 * g, v);
         }
     }
   }   // query blocks
@@ -769,8 +774,8 @@ __device__ __forceinline__ void sattn_dkv_body(const T* __restrict__ qkv, const 
         for (int dt = 0; dt < DT; ++dt) {
             float a[4] = {dk[dt][kt][0] * scale, dk[dt][kt][1] * scale, dk[dt][kt][2] * scale, dk[dt][kt][3] * scale};
             float b[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
-            store4(dkp + 16 * dt + 4 * g, a);
-            store4(dvp + 16 * dt + 4 * g, b);
+            SB_STORE4(dkp + 16 * dt + 4 * g, a);
+            SB_STORE4(dvp + 16 * dt + 4 * g, b);
         }
     }
   }   // key blocks

@@ -280,7 +280,11 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
 #ifdef ISTVT_TATTN_NOSTORE          // diagnostic: what do the backward kernel's 8-byte output stores cost?
 #define TB_STORE8(p, v) do { if (scale < -1e30f) *reinterpret_cast<bf16x8*>(p) = (v); } while (0)
 #else
+#ifdef ISTVT_TATTN_NT
+#define TB_STORE8(p, v) __builtin_nontemporal_store((v), reinterpret_cast<bf16x8*>(p))
+#else
 #define TB_STORE8(p, v) (*reinterpret_cast<bf16x8*>(p) = (v))
+#endif
 #endif
 #ifndef ISTVT_TB_WPE
 #define ISTVT_TB_WPE 4
