@@ -11,7 +11,7 @@ import istvt_pkg  # noqa: E402
 istvt_pkg.load()
 from istvt_amd import ops  # noqa: E402
 
-B, F, P, D = 32, 9, 197, 728
+B, F, P, D = 32, 9, 197, int(os.environ.get("LN_D", 728))      # LN_D: another row length (512 = one full instruction per row)
 M = B * F * P
 dt = torch.bfloat16
 reps = 20
