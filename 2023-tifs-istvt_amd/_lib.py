@@ -20,6 +20,8 @@ SIGNATURES = {
     'istvt_layernorm_fwd_diff': [P, L, P, P, P, L, P, L, P, P, I, I, I, I, F, I, P],
     'istvt_layernorm_bwd': [P, L, P, L, P, P, P, P, L, P, L, P, P, P, P, L, L, I, I, P],
     'istvt_layernorm_bwd_ws_elems': [L, I],
+    'istvt_layernorm_bwd_partial': [P, L, P, L, P, P, P, P, L, P, L, I, P, L, L, I, I, P],
+    'istvt_layernorm_bwd_reduce': [P, L, L, I, P, P, P, P],
     'istvt_attn_spatial_fwd': [P, L, P, L, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_bwd': [P, L, P, P, L, P, P, P, I, I, I, I, F, I, P],
     'istvt_attn_spatial_fwd_fp8': [P, L, P, L, P, I, I, I, I, F, I, P],

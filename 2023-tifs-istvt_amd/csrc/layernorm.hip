@@ -501,10 +501,10 @@ extern "C" int istvt_layernorm_bwd_ws_elems(long M, int D) { return (int)(ln_bwd
 // dres may be null.  dgamma / dbeta accumulate (+=); dcol (may be null) accumulates the column sums of dx.
 // ws: float workspace of at least istvt_layernorm_bwd_ws_elems(M, D) elements (per-workgroup partial sums; contents
 // are scratch).  Bit-reproducible: no floating-point atomics.
-extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, const float* mean,
-                                   const float* rstd, const float* gamma, const void* dres, long ld_res, void* dx,
-                                   long ld_dx, float* dgamma, float* dbeta, float* dcol, float* ws, long ws_elems, long M,
-                                   int D, int dtype, hipStream_t stream) {
+// the row kernel alone: dx and the per-workgroup partial rows in ws (dcol: a third accumulator, the column sums of dx)
+static int ln_bwd_launch(const void* dy, long ld_dy, const void* x, long ld_x, const float* mean, const float* rstd,
+                         const float* gamma, const void* dres, long ld_res, void* dx, long ld_dx, bool dcol, float* ws,
+                         long ws_elems, long M, int D, int dtype, hipStream_t stream) {
     if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0 || !ws) return ISTVT_ERR_SHAPE;
     if (ld_dy < D || ld_x < D || ld_dx < D || ld_dy % 8 || ld_x % 8 || ld_dx % 8) return ISTVT_ERR_SHAPE;
     if (dres && (ld_res < D || ld_res % 8)) return ISTVT_ERR_SHAPE;
@@ -540,7 +540,35 @@ extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, lo
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ln_bwd_kernel<T, false>), dim3((int)blocks), dim3(256), 0, stream,
                                                  (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)dres, (T*)dx, ws, M,
                                                  D, ld_dy, ld_x, ld_res, ld_dx));
-    int rc = istvt_check_launch();
+    return istvt_check_launch();
+}
+
+extern "C" int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, const float* mean,
+                                   const float* rstd, const float* gamma, const void* dres, long ld_res, void* dx,
+                                   long ld_dx, float* dgamma, float* dbeta, float* dcol, float* ws, long ws_elems, long M,
+                                   int D, int dtype, hipStream_t stream) {
+    const int rc = ln_bwd_launch(dy, ld_dy, x, ld_x, mean, rstd, gamma, dres, ld_res, dx, ld_dx, dcol != nullptr, ws, ws_elems,
+                                 M, D, dtype, stream);
     if (rc) return rc;
+    return istvt_rows_reduce_add(ws, (int)ln_bwd_blocks(M), dcol ? 3 : 2, D, dgamma, dbeta, dcol, stream);
+}
+
+// The two halves of istvt_layernorm_bwd for a caller that runs the fold of the partial rows elsewhere (another stream,
+// later): _partial writes dx and ws (with_dcol: also the column sums of dx), _reduce folds ws into dgamma / dbeta (/ dcol:
+// non-null exactly when the partial call had with_dcol) in the same fixed order.  Nothing on the caller's critical path
+// reads the parameter gradients, but 38 five-microsecond reduce launches per training step sat on it.
+extern "C" int istvt_layernorm_bwd_partial(const void* dy, long ld_dy, const void* x, long ld_x, const float* mean,
+                                           const float* rstd, const float* gamma, const void* dres, long ld_res, void* dx,
+                                           long ld_dx, int with_dcol, float* ws, long ws_elems, long M, int D, int dtype,
+                                           hipStream_t stream) {
+    return ln_bwd_launch(dy, ld_dy, x, ld_x, mean, rstd, gamma, dres, ld_res, dx, ld_dx, with_dcol != 0, ws, ws_elems, M, D,
+                         dtype, stream);
+}
+extern "C" int istvt_layernorm_bwd_reduce(const float* ws, long ws_elems, long M, int D, float* dgamma, float* dbeta,
+                                          float* dcol, hipStream_t stream) {
+    if (D % 8 != 0 || D > LN_MAXCH * 512 || M <= 0 || !ws || !dgamma || !dbeta) return ISTVT_ERR_SHAPE;
+    const long blocks = ln_bwd_blocks(M);
+    const int nacc = dcol ? 3 : 2;
+    if (ws_elems < blocks * nacc * D) return ISTVT_ERR_SHAPE;
     return istvt_rows_reduce_add(ws, (int)blocks, nacc, D, dgamma, dbeta, dcol, stream);
 }

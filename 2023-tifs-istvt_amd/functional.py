@@ -73,7 +73,7 @@ class LayerNormFn(Function):
             return dres, None, None, None, None, None
         dg, rg = _target(gamma)
         db, rb = _target(beta)
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True, dcol=dcol)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True, dcol=dcol, defer=_ln_defer(dy, (rg, rb)))
         return dx, rg, rb, None, None, None
 
 
@@ -108,7 +108,7 @@ class LayerNormDiffFn(Function):
             return dres, None, None, None, None, None, None
         dg, rg = _target(gamma)
         db, rb = _target(beta)
-        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True, dcol=dcol)
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dg, db, dres=dres, pad=True, dcol=dcol, defer=_ln_defer(dy, (rg, rb)))
         return dx, rg, rb, None, None, None, None
 
 
@@ -139,7 +139,7 @@ _overlap = {'on': os.environ.get('ISTVT_WGRAD_STREAM', '1') != '0', 'streams': {
             # Grouping: the weight gradients of up to 8 Linears with the same row count (one transformer layer) are queued
             # and launched as ONE (tile, split) grid (ops.linear_wgrad_group): 120 tiles need 2 reduction splits to fill
             # the chip instead of 7..42 per GEMM alone, so the fp32 partial slabs shrink from 512 MB to 60 MB per layer.
-            'group': int(os.environ.get('ISTVT_WGRAD_GROUP', '8')), 'queue': {}}
+            'group': int(os.environ.get('ISTVT_WGRAD_GROUP', '8')), 'queue': {}, 'lnq': {}}
 
 
 def set_wgrad_overlap(on: bool):
@@ -185,15 +185,25 @@ grad_ready_hooks = []
 def _flush_group(dev):
     """launch the queued weight gradients (on the side stream when the overlap is on, else on the current stream)"""
     q = _overlap['queue'].pop(dev, None)
-    if not q:
+    lq = _overlap['lnq'].pop(dev, None)          # deferred LayerNorm parameter-gradient folds (_ln_defer)
+    if not q and not lq:
         return
+
+    def launch():
+        if q:
+            ops.linear_wgrad_group(q)
+        for ent in lq or ():
+            ops.layernorm_bwd_reduce(*ent)
+
     if _overlap['on']:
         side = _side_stream(torch.device('cuda', dev))
         side.wait_stream(torch.cuda.current_stream(torch.device('cuda', dev)))
         with torch.cuda.stream(side):
-            ops.linear_wgrad_group(q)
+            launch()
     else:
-        ops.linear_wgrad_group(q)
+        launch()
+    if lq:
+        _overlap['keep'].setdefault(dev, []).append(lq)      # the workspaces: alive until the join
 
 
 def _side_stream(device):
@@ -247,6 +257,7 @@ def flush_stale_joins():
         if task == -1 or _overlap['pending'][dev][1] != task:
             if task == -1:
                 _overlap['queue'].pop(dev, None)
+                _overlap['lnq'].pop(dev, None)
             else:
                 _flush_group(dev)
             side = _overlap['streams'].get(dev)
@@ -256,15 +267,10 @@ def flush_stale_joins():
             _overlap['keep'].pop(dev, None)
 
 
-def _wgrad(dy, x, weight):
-    buf, ret = _target(weight)
-    out = buf.view(weight.shape[0], -1)
-    group = _overlap['group']
-    if not (ret is None and dy.is_cuda and (_overlap['on'] or group > 1)):
-        ops.linear_wgrad(dy, x, out=out)
-        return ret
-    dev = dy.device.index
-    main = torch.cuda.current_stream(dy.device)
+def _ensure_join(device):
+    """register the end-of-backward join of the side stream for the current backward pass (once per pass and device)"""
+    dev = device.index
+    main = torch.cuda.current_stream(device)
     task = _graph_task()
     ent = _overlap['pending'].get(dev)
     if ent is not None and ent[1] != task:
@@ -273,6 +279,35 @@ def _wgrad(dy, x, weight):
     if ent is None:
         _overlap['pending'][dev] = (main, task)
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev, task))
+    return dev, main
+
+
+_LN_DEFER = os.environ.get('ISTVT_LN_DEFER', '1') != '0'      # 0: every LayerNorm backward folds its partial rows itself
+
+
+def _ln_defer(dy, rets):
+    """The `defer` argument of ops.layernorm_bwd for a LayerNorm backward inside an autograd pass: the fold of the
+    kernel's partial rows into the parameter gradients (one 5 us launch per LayerNorm, 38 per training step, that nothing
+    on the main stream waits for) is queued and launched with the next group of weight gradients on their stream.  Only
+    when every gradient lands straight in its .grad buffer (rets all None: GradBucket(fuse_accumulate=True)) -- a tensor
+    handed back to autograd would be read before the fold has written it -- and the overlap is on."""
+    if not (_overlap['on'] and _LN_DEFER and dy.is_cuda and all(r is None for r in rets) and _graph_task() != -1):
+        return None
+    dev, _ = _ensure_join(dy.device)
+
+    def sink(ws, M, D, dgamma, dbeta, dcol):
+        _overlap['lnq'].setdefault(dev, []).append((ws, M, D, dgamma, dbeta, dcol))
+    return sink
+
+
+def _wgrad(dy, x, weight):
+    buf, ret = _target(weight)
+    out = buf.view(weight.shape[0], -1)
+    group = _overlap['group']
+    if not (ret is None and dy.is_cuda and (_overlap['on'] or group > 1)):
+        ops.linear_wgrad(dy, x, out=out)
+        return ret
+    dev, main = _ensure_join(dy.device)
     if group > 1 and out.is_contiguous() and ops.wgrad_groupable(dy, x):
         q = _overlap['queue'].get(dev)
         if q and (q[0][0].shape[0] != dy.shape[0] or any(o.data_ptr() == out.data_ptr() for _, _, o in q)):

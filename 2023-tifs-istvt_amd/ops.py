@@ -635,11 +635,14 @@ def layernorm_fwd_diff(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, B: in
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, dgamma: Tensor, dbeta: Tensor,
-                  dres: Optional[Tensor] = None, pad: bool = False, dcol: Optional[Tensor] = None) -> Tensor:
+                  dres: Optional[Tensor] = None, pad: bool = False, dcol: Optional[Tensor] = None, defer=None) -> Tensor:
     """dx of LayerNorm (+ dres, the gradient arriving through the residual fork); dgamma / dbeta (float32 [D]) accumulate;
     dcol (float32 [D], optional) accumulates the column sums of dx (the producing Linear's bias gradient).  Row-strided
     views allowed.  Reproducible: the column sums are reduced in a fixed order (per-workgroup partial rows + one
-    reduce launch), no atomics."""
+    reduce launch), no atomics.
+    defer (callable, optional): only the row kernel is launched here; the fold of the partial rows into dgamma / dbeta /
+    dcol is handed to defer(ws, M, D, dgamma, dbeta, dcol), which runs layernorm_bwd_reduce(...) with those arguments
+    wherever it likes (functional: on the weight-gradient stream) and keeps `ws` alive until that launch has run."""
     x2, ldx = rows(_req(x))
     M, D = x2.shape
     dy, ld_dy = rows(_req(dy))
@@ -651,11 +654,27 @@ def layernorm_bwd(dy: Tensor, x: Tensor, mean: Tensor, rstd: Tensor, gamma: Tens
     ws = torch.empty((lib.istvt_layernorm_bwd_ws_elems(M, D),), dtype=torch.float32, device=x.device)
     ntens = 3 + (dres is not None)          # dy, x, dx (+ dres)
     with prof('ln_bwd', ntens * M * D * x.element_size()):
-        _lib.check(lib.istvt_layernorm_bwd(dy.data_ptr(), ld_dy, x2.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
-                                           gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(), dx.stride(0) if M > 1 else D,
-                                           dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dcol), ws.data_ptr(), ws.numel(), M, D,
-                                           dtype_code(x), _stream()), 'istvt_layernorm_bwd')
+        if defer is None:
+            _lib.check(lib.istvt_layernorm_bwd(dy.data_ptr(), ld_dy, x2.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
+                                               gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(), dx.stride(0) if M > 1 else D,
+                                               dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dcol), ws.data_ptr(), ws.numel(), M, D,
+                                               dtype_code(x), _stream()), 'istvt_layernorm_bwd')
+        else:
+            _lib.check(lib.istvt_layernorm_bwd_partial(dy.data_ptr(), ld_dy, x2.data_ptr(), ldx, mean.data_ptr(),
+                                                       rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), ld_res, dx.data_ptr(),
+                                                       dx.stride(0) if M > 1 else D, int(dcol is not None), ws.data_ptr(),
+                                                       ws.numel(), M, D, dtype_code(x), _stream()),
+                       'istvt_layernorm_bwd_partial')
+    if defer is not None:
+        defer(ws, M, D, dgamma, dbeta, dcol)
     return dx if x.dim() == 2 else dx.view(*x.shape)
+
+
+def layernorm_bwd_reduce(ws: Tensor, M: int, D: int, dgamma: Tensor, dbeta: Tensor, dcol: Optional[Tensor] = None) -> None:
+    """the second half of layernorm_bwd(defer=...): folds the partial rows in `ws` into dgamma / dbeta (/ dcol), on the
+    current stream, in the same fixed order as the one-call form"""
+    _lib.check(_lib.lib().istvt_layernorm_bwd_reduce(ws.data_ptr(), ws.numel(), M, D, dgamma.data_ptr(), dbeta.data_ptr(),
+                                                     _ptr(dcol), _stream()), 'istvt_layernorm_bwd_reduce')
 
 
 def _same_rows(like: Tensor, ld: int, M: int, D: int) -> Tensor:

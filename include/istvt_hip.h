@@ -105,6 +105,15 @@ int istvt_layernorm_bwd(const void* dy, long ld_dy, const void* x, long ld_x, co
                         float* dbeta, float* dcol, float* ws, long ws_elems, long M, int D, int dtype,
                         istvt_stream_t stream);
 int istvt_layernorm_bwd_ws_elems(long M, int D);
+/* istvt_layernorm_bwd in two halves, for a caller that folds the partial rows off its critical path (another stream, or
+ * later): _partial = the row kernel alone (dx, and the per-workgroup partial rows in ws; with_dcol: a third accumulator,
+ * the column sums of dx), _reduce = the fixed-order fold of that ws into dgamma / dbeta (and dcol, non-NULL exactly when the
+ * partial call had with_dcol).  Same arithmetic and order as the one-call form: bit-identical results. */
+int istvt_layernorm_bwd_partial(const void* dy, long ld_dy, const void* x, long ld_x, const float* mean, const float* rstd,
+                                const float* gamma, const void* dres, long ld_res, void* dx, long ld_dx, int with_dcol,
+                                float* ws, long ws_elems, long M, int D, int dtype, istvt_stream_t stream);
+int istvt_layernorm_bwd_reduce(const float* ws, long ws_elems, long M, int D, float* dgamma, float* dbeta, float* dcol,
+                               istvt_stream_t stream);
 
 /* ---- spatial attention (SpatialOnlyAttention.forward core, module.py:84-91) ---------------
  * qkv [BF*P][3*heads*dh] (q|k|v, 'b n (h d)') with row stride ldqkv (elements; also dqkv's), out / dout

@@ -185,6 +185,32 @@ def layernorm_bwd_reproducible(dtype, D=728, M=20011):
     return (0.0 if same else 1.0), 0.0
 
 
+def layernorm_bwd_deferred(dtype, D=728, M=20011):
+    """ops.layernorm_bwd(defer=...) + layernorm_bwd_reduce on ANOTHER stream (how functional runs it: the fold of the
+    partial rows rides on the weight-gradient stream) gives the same bits as the one-call form, with and without dcol"""
+    x, g = rnd((M, D), dtype, 1, 2.0), rnd((D,), torch.float32, 2, 0.2) + 1
+    dy, dres = rnd((M, D), dtype, 4), rnd((M, D), dtype, 5)
+    _, mean, rstd = ops.layernorm_fwd(x, g, torch.zeros_like(g), 1e-5)
+    side = torch.cuda.Stream()
+    worst = 0.0
+    for with_dcol in (True, False):
+        dg, db, dc = (torch.full((D,), 0.25, dtype=torch.float32, device=DEV) for _ in range(3))      # accumulate (+=) onto something
+        dx = ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres, dcol=dc if with_dcol else None)
+        dg2, db2, dc2 = (torch.full((D,), 0.25, dtype=torch.float32, device=DEV) for _ in range(3))
+        held = []
+        dx2 = ops.layernorm_bwd(dy, x, mean, rstd, g, dg2, db2, dres=dres, dcol=dc2 if with_dcol else None,
+                                defer=lambda *a: held.append(a))
+        assert len(held) == 1 and torch.equal(dg2, torch.full_like(dg2, 0.25)), 'the deferred call must not touch the gradients'
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.layernorm_bwd_reduce(*held[0])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        same = torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2) and (not with_dcol or torch.equal(dc, dc2))
+        worst = max(worst, 0.0 if same else 1.0)
+    return worst, 0.0
+
+
 def frame_diff(dtype, B=2, F=7, P=13, D=64):
     x = rnd((B * F * P, D), dtype, 1)
     xd = x.double().requires_grad_(True)
@@ -394,6 +420,7 @@ def all_checks():
         for D_, M_ in ((512, 333), (520, 1003), (1024, 129), (728, 3), (728, 70001)):
             out.append(('layernorm_D%d_M%d_%s' % (D_, M_, tag), lambda dt=dt, D_=D_, M_=M_: layernorm(dt, D_, M_)))
         out.append(('layernorm_bwd_reproducible_%s' % tag, lambda dt=dt: layernorm_bwd_reproducible(dt)))
+        out.append(('layernorm_bwd_deferred_%s' % tag, lambda dt=dt: layernorm_bwd_deferred(dt)))
         out.append(('frame_diff_%s' % tag, lambda dt=dt: frame_diff(dt)))
         # (129 .. 256 keys: the keys-resident kernels incl. the fused backward -- smallest, 32-multiples, largest)
         for P, heads, dh in ((197, 8, 64), (37, 8, 64), (362, 2, 32), (362, 8, 64), (128, 2, 64), (129, 2, 64), (160, 8, 64),

@@ -837,6 +837,22 @@ def test_training_step_is_bit_reproducible(dtype):
                     bad.append((n, float((fl[off:off + k] - runs[0][1][off:off + k]).abs().max())))
                 off += k
             raise AssertionError('gradients differ between two runs of the same step: %s' % bad[:12])
+    # one stream, nothing deferred (weight gradients and the LayerNorm parameter-gradient folds in program order): same bits
+    from istvt_amd import functional as Fn
+    was = Fn._overlap['on']
+    Fn.set_wgrad_overlap(False)
+    try:
+        bucket.zero()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        logits = model(x)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), labels).backward()
+        torch.cuda.synchronize()
+    finally:
+        Fn.set_wgrad_overlap(was)
+    assert torch.equal(logits.detach(), runs[0][0]) and torch.equal(bucket.flat, runs[0][1]), \
+        'side-stream weight gradients / deferred LayerNorm folds change the bits'
 
 
 @pytest.mark.gpu
