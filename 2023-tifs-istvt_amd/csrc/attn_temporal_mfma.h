@@ -277,14 +277,19 @@ __global__ __launch_bounds__(256) void tattn_mfma_fwd_kernel(const bf16_t* __res
     }
 }
 
-#ifdef ISTVT_TATTN_NOSTORE          // diagnostic: what do the backward kernel's 8-byte output stores cost?
+// Diagnostic builds of the backward kernel (tools/build_variant.sh <out.so> attn_temporal.hip -D...; tools/tattn_bench.py):
+//   ISTVT_TATTN_NOSTORE  the output stores sit behind a condition that is never true at run time (the arithmetic stays):
+//                        the floor without stores, 50-55 us at F = 9 -- how the 8-byte partial stores of round 3 were found;
+//   ISTVT_TATTN_NT       non-temporal output stores: 85 -> 73 us alone, +0.08 ms per step in the model (not the default);
+//   ISTVT_TB_WPE=n       wavefronts per SIMD the single-tile kernel is compiled and its grid is sized for (4; 3 and 2 measured
+//                        within 4 %).  Stating it at all also stops the compiler parking values in AGPRs (176 v_accvgpr moves
+//                        per problem with the default heuristic; removing them changed nothing measurable).
+#ifdef ISTVT_TATTN_NOSTORE
 #define TB_STORE8(p, v) do { if (scale < -1e30f) *reinterpret_cast<bf16x8*>(p) = (v); } while (0)
-#else
-#ifdef ISTVT_TATTN_NT
+#elif defined(ISTVT_TATTN_NT)
 #define TB_STORE8(p, v) __builtin_nontemporal_store((v), reinterpret_cast<bf16x8*>(p))
 #else
 #define TB_STORE8(p, v) (*reinterpret_cast<bf16x8*>(p) = (v))
-#endif
 #endif
 #ifndef ISTVT_TB_WPE
 #define ISTVT_TB_WPE 4
