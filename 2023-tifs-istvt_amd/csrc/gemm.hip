@@ -422,7 +422,7 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                 const int G = pick_grid(tiles, 256);
 #define QD(n) case n: hipLaunchKernelGGL((gemm256q_kernel<0, false, n>), dim3(G), block, 0, stream, a); break;
                 switch (qdbg) {
-                    QD(1) QD(2) QD(4) QD(6) QD(8) QD(16) QD(22) QD(24) QD(48) QD(54) QD(128) QD(136) QD(129) QD(256) QD(257) QD(258) QD(260) QD(262) QD(304) QD(768) QD(774) QD(1024)
+                    QD(1) QD(2) QD(4) QD(6) QD(8) QD(16) QD(22) QD(24) QD(48) QD(54) QD(128) QD(136) QD(129) QD(256) QD(257) QD(258) QD(260) QD(262) QD(304) QD(768) QD(774) QD(1024) QD(1152)
                     default: return ISTVT_ERR_SHAPE;
                 }
 #undef QD

@@ -134,6 +134,11 @@ __device__ __forceinline__ void slot_barrier() {
 // N=2912 K=728 plain 277..283 -> 269 us, GELU 336 -> 318, N=1536 131 -> 125, bias+residual N=1024 112 -> 97; K=512 N=728
 // 51 -> 53; the train step 52.4..52.7 -> 52.1 ms (the consumers of the outputs lose nothing measurable).  sc1 (16) alone
 // +1..3 %, nt + sc1 as nt.  The stem's statistics launches (64..728-column outputs) measured 3 % slower with nt: they keep 0.
+// ISTVT_Q_DIRECT_EPI=1: the plain epilogue without its trip through LDS (see DIRECT_EPI in the kernel).  Built to test what
+// bounds the epilogue; measured no faster (the CU's store path is the floor either way), so it is OFF by default.
+#ifndef ISTVT_Q_DIRECT_EPI
+#define ISTVT_Q_DIRECT_EPI 0
+#endif
 #ifndef ISTVT_Q_SIDE_NT
 #define ISTVT_Q_SIDE_NT 0
 #endif
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[QNU * QU_BYTES + 8 * PSLAB_BYTES];
     constexpr bool HAS_SIDE = SIDE || EPI == EPI_GELU_BWD;
     constexpr bool LATE_Q3 = EPI == EPI_GELU_BWD;
+    constexpr bool DIRECT_EPI = ISTVT_Q_DIRECT_EPI != 0 && EPI == 0 && !SIDE && STATS == 0 && TM == 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, r = lane & 15;
@@ -713,6 +719,65 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
         // writes of pass p + 1 that overwrite the slab, and each pass's LDS latency (twice per pass when the reads of its
         // second half followed the arithmetic of its first) hides under the previous pass's arithmetic and stores.
         constexpr int NPASS = TM == 224 ? 7 : 8;        // the AH unit holds three row tiles per wavefront at 224 rows
+        // DIRECT (plain epilogue): no trip through LDS at all.  In the accumulator layout a lane (ge, re) holds row re,
+        // columns 16 nt + 4 ge .. + 3 of block nt -- 8 bytes of bf16 per block; v_permlane16_swap of the block pairs (0, 1)
+        // and (2, 3) leaves it with 8 CONTIGUOUS columns, 16 (2 ntp + (ge & 1)) + 8 (ge >> 1) .. + 7: one 16-byte store per
+        // pair (a wave-instruction = 16 rows x 64 contiguous bytes; the two pairs complete the rows' 128-byte lines).
+        // Why it was built (DBG 1024 / 1152 stamps, K = 728, N = 1536): the epilogue through LDS takes 6.5 k cycles per tile,
+        // 6.0 k with its stores out of range and 5.6 k with no store instruction at all -- the LDS transposition alone is
+        // 8 wavefronts x 8 passes x (4 ds_write_b128 at 13 cycles + 4 ds_read_b128 at 8) = 5.4 k cycles of the CU's LDS pipe.
+        // What it measured: 4.1-4.7 k cycles with its stores out of range, but 7.5 k with them (7.9 k as 16 rows x 64 bytes
+        // per instruction) -- whether 32 or 224 workgroups run.  128 KiB of output leave a CU at 17-20 bytes per clock
+        // however they are issued; paced by the LDS round trips (6.5 k) or queued back to back (7.5 k) that is the
+        // epilogue's floor, and launch times are equal within noise (tools/gemm_bench.py).  Kept for the record, not enabled.
+        if constexpr (DIRECT_EPI) {
+            int lane_d = lane;
+            asm volatile("" : "+v"(lane_d));
+            const int re = lane_d & 15, ge = lane_d >> 4, r1 = re & 7, hh = re >> 3;
+            const int seg = 16 * (ge & 1) + 8 * (ge >> 1);                  // this lane's 8 columns inside a 32-column half
+            // A second exchange makes every store instruction 8 rows x 128 contiguous bytes (whole lines; as 16 rows x 64
+            // bytes the stores retired slowly: epilogue 7.9 k cycles against 4.1 k with the same stores out of range):
+            // store 1 = rows 0..7 of the pass -- lanes re < 8 write their own columns 0..31 part, lanes re >= 8 the
+            // columns 32..63 part of row re - 8, fetched from that lane (DPP row_ror:8); store 2 = rows 8..15, roles swapped.
+            const int row_d = wm * 64 + r1;
+            const int rows_left_d = p.M - bm0 - row_d;
+            const int col1 = wn * 64 + seg + 32 * hh, col2 = wn * 64 + seg + 32 * (1 - hh);
+            const unsigned voff1 = bn0 + col1 < p.N ? (unsigned)((row_d * ldc + col1) * 2) : OOB;
+            const unsigned voff2 = bn0 + col2 < p.N ? (unsigned)((row_d * ldc + col2) * 2) : OOB;
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int rb = (pass >> 2) * 128 + (pass & 3) * 16;
+                u32x2_t pk[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(acc[pass][nt][j] * alpha);
+                    pk[nt] = __builtin_bit_cast(u32x2_t, o);
+                }
+                u32x4 half[2];                                              // [0]: columns 0..31 part, [1]: columns 32..63 part (row re)
+#pragma unroll
+                for (int ntp = 0; ntp < 2; ++ntp) {
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(pk[2 * ntp][0], pk[2 * ntp + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * ntp][1], pk[2 * ntp + 1][1], false, false);
+                    half[ntp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+                u32x4 held[2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // the partner lane (re ^ 8, same ge) gives the part this lane stores for it
+                    const unsigned x1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)half[1][q], 0x128, 0xf, 0xf, false);
+                    held[0][q] = hh ? x1 : half[0][q];                    // rows 0..7: own left part | partner's right part
+                    held[1][q] = hh ? half[0][q] : x1;                    // rows 8..15: own left part (re >= 8) | partner's right part
+                }
+                const unsigned v1 = (rb < rows_left_d && !(DBG & 128)) ? voff1 : OOB;
+                const unsigned v2 = (rb + 8 < rows_left_d && !(DBG & 128)) ? voff2 : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(held[0], c_rs, v1, rb * ldc * 2, ISTVT_Q_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(held[1], c_rs, v2, (rb + 8) * ldc * 2, ISTVT_Q_STORE_AUX);
+                asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1])::"memory");      // STORE-DATA HAZARD, gemm_shared.h
+            }
+        } else {
         f32x4 xlo[2][2], xhi[2][2];
         auto slab_trip = [&](const int pass) {
 #pragma unroll
@@ -800,6 +865,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
             else
                 asm volatile("s_nop 15\n\ts_nop 15" : "+v"(held[0]), "+v"(held[1])::"memory");
         }
+        }   // !DIRECT_EPI
 #undef QRB
         if constexpr ((DBG & 1280) != 0) {
             // the epilogue as the wavefront sees it: its last store ISSUED (no drain: the stores retire under the next tile)
