@@ -793,9 +793,13 @@ def test_bench_two_rank_path_rehearsal():
     # ONE run times both collective schedules and names the headline one
     sch = out['distributed']['schedules']
     assert set(sch) == {'early_two_piece_allreduce', 'single_blocking_allreduce'}
-    assert sch['early_two_piece_allreduce']['headline'] and not sch['single_blocking_allreduce']['headline']
+    # exactly one schedule is the line's value: the one that measured faster (in this gloo rehearsal either may win)
+    heads = [k for k, v in sch.items() if v['headline']]
+    assert len(heads) == 1 and sch[heads[0]]['ms_per_step'] == min(v['ms_per_step'] for v in sch.values())
+    assert abs(out['ms_per_step'] - sch[heads[0]]['ms_per_step']) < 1e-2
     assert all(len(v['per_rank_ms_per_step']) == 2 and v['ms_per_step'] > 0 for v in sch.values())
-    assert out['distributed']['collectives_per_step'] == 2 and out['config']['final_norm_class_rows_only'] is True
+    assert out['distributed']['collectives_per_step'] == (1 if heads[0] == 'single_blocking_allreduce' else 2)
+    assert out['config']['final_norm_class_rows_only'] is True
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
