@@ -8,6 +8,7 @@ device: there is deliberately no CPU path.
 from __future__ import annotations
 
 import os
+import sys
 import weakref
 from typing import Optional, Tuple
 
@@ -133,6 +134,17 @@ def refresh_stale_operands() -> int:
             continue
         ver = _versions(ws)
         if hit[1] != ver:
+            # Rewritten IN PLACE only when nothing but the two caches (and this loop) holds the operand or its transpose.  A
+            # live autograd graph that saved them (ctx attributes or save_for_backward of RepChainFn / StemFn / LinearFn:
+            # forward A -> optimizer step -> forward B -> backward A) must still find forward A's weights: those copies are
+            # left alone -- dropped from the caches, so the next use makes fresh ones -- and die with the graph.
+            # (references: out = _operands tuple + _wcache tuple + `out` here + getrefcount's argument = 4; wt likewise
+            #  with its own _wcache entry; _use_count() counts C++ holders such as SavedVariable.)
+            if (sys.getrefcount(out) > 4 or sys.getrefcount(wt) > 4 or out._use_count() > 1 or wt._use_count() > 1):
+                _operands.pop(key, None)
+                _wcache.pop(key, None)
+                _wcache.pop((id(out), 'T'), None)
+                continue
             todo.append((key, ws, out, wt, ver, hit))
     if not todo:
         return 0
@@ -202,7 +214,8 @@ def weight_as(w: Tensor, dtype: torch.dtype, pad: bool = False) -> Tensor:
                                                out.stride(0), R, C, _stream()), 'istvt_cast2d')
     else:
         out = cast(w2, dtype)
-    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache: c.pop(k, None)), _versions((w,)), out)
+    # (the parameter's death drops the operand copies at once, not at the next refresh_stale_operands())
+    _wcache[key] = (weakref.ref(w, lambda _r, k=key, c=_wcache, o=_operands: (c.pop(k, None), o.pop(k, None))), _versions((w,)), out)
     return out
 
 
@@ -243,7 +256,7 @@ def weight_cat_as(ws, dtype: torch.dtype) -> Tensor:
         tkey = (id(out), 'T')
         _wcache[tkey] = (weakref.ref(out, lambda _r, k=tkey, c=_wcache: c.pop(k, None)), 0, wt)
         _operands[key] = (tuple(weakref.ref(w) for w in ws), out, wt)
-    drop = lambda _r, k=key, c=_wcache: c.pop(k, None)
+    drop = lambda _r, k=key, c=_wcache, o=_operands: (c.pop(k, None), o.pop(k, None))
     _wcache[key] = (tuple(weakref.ref(w, drop) for w in ws), ver, out)
     return out
 

@@ -236,3 +236,57 @@ def test_temporal_bf16_correlated_frames_tracks_float32():
     # from bf16 V (any bfloat16 attention has that floor); the differenced-operand path removes the q / k share of it.
     assert new_y < 8e-3 and new_y <= old_y * 1.02, (new_y, old_y)
     assert new_dx < 0.75 * old_dx, (new_dx, old_dx)
+
+
+@pytest.mark.gpu
+def test_operand_refresh_spares_operands_held_by_a_live_graph():
+    """ops.refresh_stale_operands() re-casts the cached bf16 operand copies (W and W^T) IN PLACE after an
+    optimizer step -- but not those a live autograd graph still holds (forward A -> step -> forward B -> backward A must see
+    A's weights): such copies are dropped from the caches and left intact; the steady-state loop keeps the one grouped
+    launch; a dead parameter releases its copies at once."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import ops
+    w = torch.nn.Parameter(torch.randn(256, 728, device='cuda'))
+    op = ops.weight_as(w, torch.bfloat16, pad=True)
+    opt = ops._transposed_operand(op)
+    key = (id(w), 'p')
+    assert key in ops._operands and ops._operands[key][1] is op and ops._operands[key][2] is opt
+    before = op.clone()
+    with torch.no_grad():
+        w.add_(1.0)                                    # "optimizer step": bumps _version
+    del op, opt
+    assert ops.refresh_stale_operands() == 1           # steady state: rewritten in place by the grouped launch
+    op = ops.weight_as(w, torch.bfloat16, pad=True)
+    assert ops._operands[key][1] is op and not torch.equal(op, before)
+    assert torch.equal(op, w.detach().to(torch.bfloat16))
+
+    class Hold(torch.autograd.Function):              # a Function that keeps the operand for its backward
+        @staticmethod
+        def forward(ctx, x, o):
+            ctx.save_for_backward(o)
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, None
+    x = torch.ones(3, device='cuda', requires_grad=True)
+    y = Hold.apply(x, op)
+    snap = op.clone()
+    with torch.no_grad():
+        w.add_(1.0)
+    held = op
+    del op
+    assert ops.refresh_stale_operands() == 0 and key not in ops._operands      # not rewritten: dropped from the caches
+    torch.cuda.synchronize()
+    assert torch.equal(held, snap)                                              # forward A's operand is intact
+    fresh = ops.weight_as(w, torch.bfloat16, pad=True)
+    assert fresh is not held and torch.equal(fresh, w.detach().to(torch.bfloat16))
+    y.sum().backward()
+    del y, held, fresh
+    n0 = len(ops._operands)
+    assert key in ops._operands
+    del w
+    import gc
+    gc.collect()
+    assert key not in ops._operands and len(ops._operands) == n0 - 1            # the parameter died: copies released
