@@ -1043,6 +1043,13 @@ def all_checks():  # noqa: F811
     out.append(('attn_temporal_prediff_padded_F9_bf16', lambda: attn_temporal(torch.bfloat16, 2, 9, 37, 8, 64, pad=True, diff=2, packed=True)))
     out.append(('attn_temporal_prediff_padded_F17_bf16', lambda: attn_temporal(torch.bfloat16, 2, 17, 19, 8, 64, pad=True, diff=2, packed=True)))
     out.append(('attn_temporal_prediff_F5_h2_d32_bf16', lambda: attn_temporal(torch.bfloat16, 3, 5, 11, 2, 32, diff=2)))
+    # every frame count around the boundaries of the row-chunk stores (3 F dh/8 chunks, 64 per instruction), of the 16-row
+    # tiles and of the one- / two-tile kernels, with both head sizes; NaN pad columns catch a chunk stored past a row
+    for F_ in (1, 2, 3, 7, 8, 10, 15, 16, 17):           # (the host wrappers take at most 17 frames: T <= 16)
+        out.append(('attn_temporal_store_sweep_F%d_d64_bf16' % F_,
+                    lambda F_=F_: attn_temporal(torch.bfloat16, 2, F_, 5, 2, 64, pad=True, diff=2, packed=True)))
+        out.append(('attn_temporal_store_sweep_F%d_d32_bf16' % F_,
+                    lambda F_=F_: attn_temporal(torch.bfloat16, 2, F_, 3, 4, 32, pad=True, diff=1, packed=True)))
     out.append(('layernorm_diff_bf16', lambda: layernorm_diff(torch.bfloat16)))
     out.append(('layernorm_diff_f32', lambda: layernorm_diff(torch.float32)))
     out.append(('layernorm_diff_F17_bf16', lambda: layernorm_diff(torch.bfloat16, 2, 17, 197)))
