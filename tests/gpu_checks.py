@@ -1053,6 +1053,10 @@ def all_checks():  # noqa: F811
     out.append(('layernorm_diff_bf16', lambda: layernorm_diff(torch.bfloat16)))
     out.append(('layernorm_diff_f32', lambda: layernorm_diff(torch.float32)))
     out.append(('layernorm_diff_F17_bf16', lambda: layernorm_diff(torch.bfloat16, 2, 17, 197)))
+    # C2's size (more positions than wavefronts: the walk over (clip, position) runs rounds) and odd small geometries
+    out.append(('layernorm_diff_production_C2_bf16', lambda: layernorm_diff(torch.bfloat16, 32, 9, 197)))
+    out.append(('layernorm_diff_F2_P1_bf16', lambda: layernorm_diff(torch.bfloat16, 5, 2, 1)))
+    out.append(('layernorm_diff_F1_bf16', lambda: layernorm_diff(torch.bfloat16, 4, 1, 7)))
     out.append(('gemm_cu_reserve_bit_identical', gemm_cu_reserve))
     out.append(('gemm_a_select', gemm_a_select))
     out.append(('gemm_a_select_tall', lambda: gemm_a_select(56736, 728, 1536, 1024)))
