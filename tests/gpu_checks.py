@@ -706,6 +706,8 @@ def all_checks():  # noqa: F811
         out.append(('stem_bn_c32_%s' % tag, lambda dt=dt: bn_check(dt, 20000, 32)))
         out.append(('stem_pool_%s' % tag, lambda dt=dt: pool_check(dt)))
         out.append(('stem_pool_even_%s' % tag, lambda dt=dt: pool_check(dt, 2, 28, 28, 256)))
+        if dt == torch.bfloat16:        # more quads than the backward's resident grid has threads: its quad loop runs rounds (32-bit index arithmetic)
+            out.append(('stem_pool_many_quads_%s' % tag, lambda dt=dt: pool_check(dt, 48, 109, 109, 64)))
         if dt == torch.float32:
             # 96^2 -> 6x6 output: so few samples per channel that ONE ReLU mask decided differently at
             # |z| ~ 1e-5 (fp32 summation-order noise) moves early-layer gradients by a few percent.
