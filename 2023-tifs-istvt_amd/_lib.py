@@ -60,7 +60,6 @@ SIGNATURES = {
     'istvt_splitk_reduce': [P, I, L, P, P],
     'istvt_wgrad_group': [I, P, P, P, P, P, P, P, I, I, P, L, P],
     'istvt_wgrad_group_splits': [I, P, P, I],
-    'istvt_set_cu_reserve': [I],
     'istvt_colsum': [P, P, L, I, L, P, L, I, P],
     'istvt_colsum_ws_elems': [L, I],
     'istvt_rows_reduce': [P, I, L, P, P],

@@ -848,24 +848,15 @@ extern "C" int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, lo
         if (pers && dh == 64 && P > CHUNK && P <= 240 && ldqkv * 2 * P < 0x7fffffffL) {
             // persistent form: one 16-wavefront workgroup per CU walks the (frame, head) problems, the next problem's K / V
             // arriving by LDS-DMA under the current one's arithmetic (attn_spatial_pers.h)
-            static int cus = 0;
-            if (cus == 0) {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-                cus = n;
-            }
+            const int cus = istvt_device_cus();
             const int nprob = BF * heads, ntt = (P - CHUNK + 15) / 16;
             const dim3 pgrid(nprob < cus ? nprob : cus);
 #define SP_LAUNCH(NTTV)                                                                                                   \
             case NTTV: {                                                                                                  \
-                static bool attr_set = false;                                                                              \
-                if (!attr_set) {                                                                                           \
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sattn_fwd_pers_kernel<64, NTTV>),                \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * spers::IMG_B) != hipSuccess)   \
-                        return ISTVT_ERR_LAUNCH;                                                                           \
-                    attr_set = true;                                                                                       \
-                }                                                                                                          \
+                static std::atomic<unsigned long long> lds_raised{0};                                                      \
+                if (istvt_raise_lds_limit(lds_raised, reinterpret_cast<const void*>(sattn_fwd_pers_kernel<64, NTTV>),      \
+                                          4 * spers::IMG_B) != ISTVT_OK)                                                   \
+                    return ISTVT_ERR_LAUNCH;                                                                               \
                 hipLaunchKernelGGL((sattn_fwd_pers_kernel<64, NTTV>), pgrid, dim3(1024), 4 * spers::IMG_B, stream,          \
                                    (const bf16_t*)qkv, (bf16_t*)out, lse, nprob, P, heads, scale, ldqkv, ldo);            \
             } break;

@@ -66,6 +66,37 @@ static inline int istvt_check_launch() {
     return e == hipSuccess ? ISTVT_OK : -(1000 + (int)e);
 }
 
+// Compute units of the CALLING THREAD'S CURRENT DEVICE (the one a launch on the caller's stream runs on), 256 when the
+// runtime cannot say.  A device's CU count never changes, so the per-device slots below are write-once caches of an
+// immutable value (relaxed atomics: two threads that race store the same number); nothing about the process's state --
+// which device is current, how many devices it uses -- is remembered between calls (re-entrant entry points).
+#include <atomic>
+static inline int istvt_device_cus() {
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    if (dev < MAXDEV) {
+        const int hit = cache[dev].load(std::memory_order_relaxed);
+        if (hit > 0) return hit;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    if (dev < MAXDEV) cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+// Raise a kernel's dynamic-LDS limit above 64 KiB once per (kernel instantiation, device): `done` is that instantiation's
+// bitmask of the devices already served (a write-once flag per device, idempotent under a race).
+static inline int istvt_raise_lds_limit(std::atomic<unsigned long long>& done, const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_relaxed) & bit)) return ISTVT_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ISTVT_ERR_LAUNCH;
+    if (dev < 64) done.fetch_or(bit, std::memory_order_relaxed);
+    return ISTVT_OK;
+}
+
 #define DISPATCH_DTYPE(dtype, ...)                         \
     do {                                                   \
         if ((dtype) == DT_F32) { typedef float T; __VA_ARGS__; }       \

@@ -303,18 +303,12 @@ static int launch_gemm(const GemmArgs& a, int a_kc, int b_kc, int splitk, hipStr
     return istvt_check_launch();
 }
 
-// CUs the persistent NT kernel leaves alone (istvt_set_cu_reserve): while a collective's kernels hold CUs, a persistent
-// workgroup dealt to one of them would start only when another workgroup has finished its whole tile list and the launch
-// would take up to twice as long; with the grid cut to the CUs that are really free every workgroup is resident at once
-// (666 tiles on 224 workgroups are the same three rounds as on 256).
-static int g_cu_reserve = 0;
-extern "C" int istvt_set_cu_reserve(int n) {
-    if (n < 0 || n > 192) return ISTVT_ERR_SHAPE;
-    const int old = g_cu_reserve;
-    g_cu_reserve = n;
-    return old;
-}
-
+// CUs the persistent NT kernel leaves alone: bits 8..15 of istvt_gemm's `flags`, in units of 8 CUs -- an argument of the
+// launch, not state of the library (the entry points hold no global mutable state; the autograd thread and
+// the main thread launch concurrently).  While a collective's kernels hold CUs, a persistent workgroup dealt to one of them
+// would start only when another workgroup has finished its whole tile list and the launch would take up to twice as
+// long; with the grid cut to the CUs that are really free every workgroup is resident at once (666 tiles on 224
+// workgroups are the same three rounds as on 256).
 extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc,
                           int M, int N, int K, const float* bias, const void* residual, long ldr, void* C2, int epi,
                           int out_mode, int splitk, float alpha, double* col_sum, double* col_sumsq, int flags, int dtype,
@@ -333,6 +327,8 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.st_sum = col_sum; a.st_sumsq = col_sumsq;
     a.blocked = flags & 1;
     const bool a_sel = (flags & 2) != 0;
+    const int cu_reserve = ((flags >> 8) & 0xff) * 8;
+    if (cu_reserve > 192) return ISTVT_ERR_SHAPE;
     if (a_sel) {
         a.a_sel_col = ((flags >> 16) & 0xffff) * 64;
         a.a2_off = (int)((long)M * lda * 2);
@@ -372,14 +368,8 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
                           (long)K * lda * 2 < 0x7fffffffL && (long)K * ldb * 2 < 0x7fffffffL;
         if (q_ok) {
             // persistent NT kernel: one workgroup per CU walks its tiles with the LDS ring kept full across tiles
-            static int cus_dev = 0;
-            if (cus_dev == 0) {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-                cus_dev = n & ~7;
-            }
-            const int cus = std::max(8, (cus_dev - g_cu_reserve) & ~7);      // the CUs this launch may fill (istvt_set_cu_reserve)
+            const int cus_dev = istvt_device_cus() & ~7;
+            const int cus = std::max(8, (cus_dev - cu_reserve) & ~7);      // the CUs this launch may fill (flags bits 8..15)
             // Balanced rounds: 666 tiles on 256 CUs are three rounds whichever way they are dealt; dealing them to 224
             // workgroups (3 tiles each) takes the same time and leaves 32 CUs free for the whole launch -- for the
             // weight-gradient GEMM running on the side stream -- instead of 102 CUs free for the last round only.

@@ -88,11 +88,13 @@ class STTransformer(nn.Module):
             x = attn_s(y_t, hw=hw, residual=x_res, sink=s_t, defer_bias=s_s is not None)
             x = ff(x, residual='input', sink=s_s, defer_bias=s_f is not None)
             prev = s_f
-        if cls_of is not None:
-            # DSTTr only reads row (b, frame 0, token 0) of the final LayerNorm (vivit.py:144-146): LayerNorm is
-            # row-wise, so normalising just those rows is bit-identical and skips 99.9 % of the pass
-            x = Fn.TakeClsFn.apply(x, *cls_of)
-        return Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        # The reference normalises every row and DSTTr then reads one per clip (vivit.py:100,144-146): the default does the
+        # same.  LayerNorm is row-wise, so normalising only the rows that are read gives the same bits; like every other
+        # skipped-dead-work shortcut it belongs to the opt-in dead_row_elimination, not to the default model.
+        if cls_of is not None and self.dead_row_elimination:
+            return Fn.layer_norm(Fn.TakeClsFn.apply(x, *cls_of), self.norm.weight, self.norm.bias, self.norm.eps)
+        x = Fn.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return Fn.TakeClsFn.apply(x, *cls_of) if cls_of is not None else x
 
 
 class DSTTr(nn.Module):

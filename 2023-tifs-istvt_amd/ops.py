@@ -358,7 +358,8 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
                                stats[0, 0].data_ptr() if stats is not None else None,
                                stats[0, 1].data_ptr() if (stats is not None and csum is None) else None,
-                               int(bool(blocked)) | ((2 | ((a_sel_col // 64) << 16)) if a_sel_col else 0),
+                               int(bool(blocked)) | ((2 | ((a_sel_col // 64) << 16)) if a_sel_col else 0)
+                               | ((_cu_reserve.get(A.device.index, 0) >> 3) << 8 if _cu_reserve else 0),
                                dtype_code(A), _stream())
     if prof is not None:
         ev1.record()
@@ -368,13 +369,28 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
     _lib.check(rc, 'istvt_gemm')
 
 
-def set_cu_reserve(n: int) -> int:
-    """CUs the persistent NT GEMM launches issued from now on leave free (istvt_set_cu_reserve); returns the previous
-    value.  parallel.GradBucket raises it while its asynchronous all-reduce is in flight."""
-    rc = _lib.lib().istvt_set_cu_reserve(int(n))
-    if rc < 0:
-        _lib.check(rc, 'istvt_set_cu_reserve')
-    return rc
+# CUs the persistent NT GEMM launches leave free, per device index: an ARGUMENT of every istvt_gemm call (flags bits
+# 8..15), not state of the library.  Python-side dict, read and written under the GIL by the main thread (all_reduce) and
+# the autograd thread (the early all-reduce hook).
+_cu_reserve: dict = {}
+
+
+def set_cu_reserve(n: int, device=None) -> int:
+    """CUs (a multiple of 8, at most 192) that the persistent NT GEMM launches issued on `device` from now on leave free;
+    returns the previous value so the caller can restore it.  parallel.GradBucket raises it while its asynchronous
+    all-reduce is in flight.  The value travels with each launch (istvt_gemm flags)."""
+    n = int(n)
+    if n < 0 or n > 192:
+        raise RuntimeError('set_cu_reserve: %d is outside 0..192' % n)
+    idx = torch._C._cuda_getDevice() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    old = _cu_reserve.get(idx, 0)
+    _cu_reserve[idx] = (n + 7) & ~7
+    return old
+
+
+def get_cu_reserve(device=None) -> int:
+    idx = torch._C._cuda_getDevice() if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    return _cu_reserve.get(idx, 0)
 
 
 def stats_fusable(x: Tensor, w: Tensor) -> bool:

@@ -71,7 +71,7 @@ class GradBucket:
         # CUs left to the collective's kernels while the early all-reduce overlaps the stem backward (RCCL runs one
         # workgroup per channel; the persistent GEMM kernels need whole CUs).  ISTVT_RCCL_CU_RESERVE overrides.
         self.cu_reserve = int(os.environ.get('ISTVT_RCCL_CU_RESERVE', '32'))
-        self._reserved = False
+        self._reserved = None           # (device index, value before ours) while the reserve is raised
         self._on_ready = None
         self.flat_params = None
         if flatten_params:
@@ -88,9 +88,11 @@ class GradBucket:
 
     def zero(self):
         # weight gradients of a backward pass that aborted may still be queued on the side stream: they must land
-        # before the zero fill, not after it
+        # before the zero fill, not after it; so must an early all-reduce that such a backward started and no
+        # all_reduce() call collected (it also still holds the CU reserve)
         from . import functional as Fn
         Fn.flush_stale_joins()
+        self._drop_early_work()
         self.flat.zero_()
 
     def enable_early_all_reduce(self, first_param: int, group=None):
@@ -104,7 +106,7 @@ class GradBucket:
         if not all(getattr(p, '_istvt_fused_grad', False) for p in self.params[first_param:]):
             raise ValueError('enable_early_all_reduce needs GradBucket(..., fuse_accumulate=True)')
         lo = sum(p.numel() for p in self.params[:first_param])
-        self._early_work = None
+        self._drop_early_work()
         self.disable_early_all_reduce()
         self._early = (lo, self.numel, group)
         ref = weakref.ref(self)          # the global hook list must not keep a dropped bucket (and its collectives) alive
@@ -131,22 +133,46 @@ class GradBucket:
             # beside it, are launched on the CUs that are left (ops.set_cu_reserve), reset in all_reduce()
             if device.type == 'cuda' and me.cu_reserve > 0:
                 from . import ops
-                ops.set_cu_reserve(me.cu_reserve)
-                me._reserved = True
+                me._reserved = (device.index, ops.set_cu_reserve(me.cu_reserve, device.index))
 
         self._on_ready = on_ready
         Fn.grad_ready_hooks.append(on_ready)
 
+    def _release_cus(self):
+        """put back the CU reserve that the early all-reduce hook raised (the value found then, not 0)"""
+        if self._reserved is not None:
+            from . import ops
+            idx, prev = self._reserved
+            self._reserved = None
+            ops.set_cu_reserve(prev, idx)
+
+    def _drop_early_work(self):
+        """an early collective nobody will wait for through all_reduce() (re-arming, a backward that aborted after the
+        hook): wait for it here so it cannot write into the bucket later, and give the CUs back"""
+        if self._early_work is not None:
+            work, _ = self._early_work
+            self._early_work = None
+            try:
+                work.wait()
+            except Exception:       # noqa: BLE001  (a torn-down process group)
+                pass
+        self._release_cus()
+
     def disable_early_all_reduce(self):
+        """No early collective is started from the next backward on.  One already in flight stays owned by the
+        all_reduce() call that follows (which also returns its CUs)."""
         from . import functional as Fn
         if self._on_ready is not None and self._on_ready in Fn.grad_ready_hooks:
             Fn.grad_ready_hooks.remove(self._on_ready)
         self._on_ready = None
         self._early = None
+        if self._early_work is None:
+            self._release_cus()
 
     def __del__(self):
         try:
             self.disable_early_all_reduce()
+            self._release_cus()
         except Exception:           # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -178,10 +204,7 @@ class GradBucket:
         if self._early_work is not None:    # the transformer's slice is already in flight (enable_early_all_reduce)
             work, lo = self._early_work     # (lo travels with the work: disable_early_all_reduce() may have run since)
             self._early_work = None
-            if self._reserved:
-                from . import ops
-                ops.set_cu_reserve(0)           # what is launched from here on runs after the collective (work.wait())
-                self._reserved = False
+            self._release_cus()                 # what is launched from here on runs after the collective (work.wait())
             if lo > 0:
                 dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM, group=group)
             work.wait()

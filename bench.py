@@ -29,13 +29,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch is imported by main() AFTER the decision to self-launch: the parent of a `--gpus N` job that starts its own ranks
+# never imports torch, so it cannot load -- let alone initialise -- the HIP runtime before it spawns them.
+torch = None
+dist = None
+
+
+def _import_torch():
+    global torch, dist
+    if torch is None:
+        import torch as _t
+        import torch.distributed as _d
+        torch, dist = _t, _d
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s is the measured copy rate)
 GF_PER_CLIP_FWD_BWD = {8: 1021.1, 16: 1938.7}     # SURVEY.md 8(a), T=8 / T=16 at 224^2, depth 12
+GF_PER_CLIP_NATIVE = 1483.5                       # the reference's own geometry, T=6, 300^2, depth 12
 
 
 def parse():
@@ -68,10 +79,11 @@ def parse():
     ap.add_argument('--config', default=None, choices=['C1', 'C2', 'C3', 'C4', 'C5'],
                     help='a BASELINE.json configuration by name: C1 1-clip T=4 96^2 depth-2 float32, C2 (default) B=32 T=8 224^2 bf16, '
                          'C3 = C2 per GPU on 8 GPUs (use with --gpus 8), C4 T=16, C5 B=64 with fp8 spatial-attention operands')
-    ap.add_argument('--host-boundary', action='store_true',
-                    help='extra field with_host_boundary: the same K steps with the reference loop\'s host side in the timed '
-                         'region (train_CNN.py:506,512,534-536): per-step H2D copy of the (B,T,3,S,S) batch from pinned memory '
-                         '(double-buffered on a copy stream), loss.item() and the accuracy count; NOT the headline value')
+    ap.add_argument('--host-boundary', action='store_true', default=True,
+                    help='(default) extra field with_host_boundary: the same K steps with the reference loop\'s host side in the '
+                         'timed region (train_CNN.py:506,512,534-536): per-step H2D copy of the (B,T,3,S,S) batch from pinned '
+                         'memory (double-buffered on a copy stream), loss.item() and the accuracy count; NOT the headline value')
+    ap.add_argument('--no-host-boundary', dest='host_boundary', action='store_false', help='skip the with_host_boundary leg')
     ap.add_argument('--keep-schedule', action='store_true',
                     help='N > 1: report the default (early, two-piece) all-reduce schedule even if the single blocking one measured faster')
     ap.add_argument('--rccl-rehearsal', action='store_true',
@@ -97,6 +109,9 @@ def parse():
                          '(train_CNN.py:185-186); here it means one process per device (= --gpus N)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short C4 / C5 / C1 legs that fill the other_configs field of the default run')
+    ap.add_argument('--self-launch', action='store_true',
+                    help='start the rank(s) through the self-launcher even for --gpus 1 (what --gpus N > 1 does without '
+                         'WORLD_SIZE in the environment): the launcher path of the multi-GPU run, testable on a one-GPU box')
     ap.add_argument('--plumbing-only', action='store_true',
                     help='exercise only the launch / process-group / timing / JSON plumbing (no model, no GPU needed): '
                          'what the CPU test of the self-launching --gpus N path runs')
@@ -132,19 +147,63 @@ def apply_reference_flags(a):
     return a
 
 
+def visible_gpus():
+    """(count, source) of the GPUs this process could use, WITHOUT touching the HIP runtime or torch: the *_VISIBLE_DEVICES
+    lists if set (the smallest one wins, as the runtime applies them in turn), else the KFD topology in sysfs (nodes with
+    simd_count > 0 are GPUs; CPUs have 0).  (None, reason) when neither can be read: the ranks then find out themselves."""
+    counts = []
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            counts.append((len([t for t in v.split(',') if t.strip() != '']), var))
+    topo = '/sys/class/kfd/kfd/topology/nodes'
+    n_kfd = None
+    try:
+        n_kfd = 0
+        for node in os.listdir(topo):
+            try:
+                with open(os.path.join(topo, node, 'properties')) as fh:
+                    for line in fh:
+                        k, _, v = line.partition(' ')
+                        if k == 'simd_count':
+                            n_kfd += int(v) > 0
+                            break
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        n_kfd = None
+    if counts:
+        n, var = min(counts)
+        if n_kfd is not None:
+            n = min(n, n_kfd)
+        return n, var
+    if n_kfd is not None:
+        return n_kfd, 'kfd topology (sysfs)'
+    return None, 'unknown (no *_VISIBLE_DEVICES, no /sys/class/kfd)'
+
+
+def hip_runtime_mapped():
+    """whether libamdhip64 is mapped into THIS process (it must not be in the self-launching parent)"""
+    try:
+        with open('/proc/self/maps') as fh:
+            return any('libamdhip64' in line for line in fh)
+    except OSError:
+        return None
+
+
 def self_launch(a):
-    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks ourselves, exactly as
-    the documented launch line does, and hand back rank 0's JSON line and the job's exit code.  The parent never
-    touches the GPU (nothing above this call initialises HIP; torch.cuda.device_count() does not either) and does not
-    exec: the ranks are child processes with inherited stdout / stderr.  The reference's own multi-device mode needs
-    no launcher (nn.DataParallel, train_CNN.py:185-186); this keeps `--gpus N` as easy to start."""
+    """`python bench.py --gpus N` (N > 1, or --self-launch) started WITHOUT torch.distributed.run: start the N ranks
+    ourselves, exactly as the documented launch line does, and hand back rank 0's JSON line and the job's exit code.
+    The parent never touches the GPU: it has not imported torch (see _import_torch), it counts devices from the
+    environment / sysfs (visible_gpus) and it does not exec -- the ranks are child processes with inherited stdout /
+    stderr.  The reference's own multi-device mode needs no launcher (nn.DataParallel, train_CNN.py:185-186); this keeps
+    `--gpus N` as easy to start."""
     import socket
     import subprocess
     rehearsal = bool(os.environ.get('ISTVT_BENCH_REHEARSAL')) or a.plumbing_only
-    if not rehearsal:
-        have = torch.cuda.device_count()
-        if have < a.gpus:
-            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (a.gpus, have))
+    have, source = visible_gpus()
+    if not rehearsal and have is not None and have < a.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (%s)' % (a.gpus, have, source))
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -153,6 +212,10 @@ def self_launch(a):
     env['MASTER_ADDR'] = '127.0.0.1'
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // a.gpus)))
     env.setdefault('ISTVT_PIN_RANKS', '1')      # each rank binds itself to its own share of the cores (pin_rank below)
+    # what the parent saw, for rank 0's JSON line (`launcher`)
+    env['ISTVT_BENCH_LAUNCHER'] = json.dumps({'self_launched': True, 'visible_gpus': have, 'visible_gpus_source': source,
+                                              'parent_imported_torch': 'torch' in sys.modules,
+                                              'parent_mapped_hip_runtime': hip_runtime_mapped()})
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
@@ -195,6 +258,7 @@ def plumbing_only(a, world, rank):
     if rank == 0:
         print(json.dumps({'plumbing_only': True, 'metric': 'none (launch plumbing check)', 'value': 0.0, 'unit': 'clips/s',
                           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                          'launcher': json.loads(os.environ.get('ISTVT_BENCH_LAUNCHER', '{"self_launched": false}')),
                           'distributed': {'backend': dist.get_backend() if world > 1 else None,
                                           'ranks': dist.get_world_size() if world > 1 else 1,
                                           'per_rank_s': [round(t, 4) for t in per_rank]}}), flush=True)
@@ -243,7 +307,25 @@ def cpu_baseline(frames, size, depth, clips=2, reps=3):
     d1 = sorted(t1)[len(t1) // 2]
     c1 = {'value': round(1.0 / d1, 3), 'unit': 'clips/s', 'ms': round(d1 * 1e3, 1),
           'sample': 'C1: 1 clip, T=4, 96x96, depth 2, forward, fp32, train-mode BatchNorm; 1 warm-up + 5 repetitions, median'}
-    return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port', 'c1_forward': c1,
+    # the reference's own geometry (T=6, 300x300, 19x19 grid, depth 12), the CPU leg of other_configs.native: 1 clip fwd+bwd
+    nat = None
+    if (frames, size, depth) == (8, 224, 12):
+        gn = R.stem_out_side(300)
+        shn = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
+        shn.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(6, gn, depth=12).items()})
+        pn0 = R.random_params(shn, seed=0)
+        xn = torch.randn((1, 6, 3, 300, 300), generator=torch.Generator().manual_seed(0))
+        tn = []
+        for rep in range(3):
+            pn = R.with_grad(pn0)
+            t0 = time.perf_counter()
+            R.bce_with_logits(R.xception_vidtr_forward(pn, xn, depth=12), torch.ones(1)).backward()
+            if rep > 0:
+                tn.append(time.perf_counter() - t0)
+        dn = min(tn)
+        nat = {'value': round(1.0 / dn, 4), 'unit': 'clips/s', 's_per_clip': round(dn, 2),
+               'sample': 'native: 1 clip, T=6, 300x300, depth 12, fwd+bwd fp32; 1 warm-up + 2 repetitions, best'}
+    return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port', 'c1_forward': c1, 'native': nat,
             'sample': 'batch of %d clips (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads: 1 warm-up + '
                       '%d repetitions, median %.1f s (all: %s)' % (clips, frames, size, size, depth, torch.get_num_threads(), reps,
                                                                  dt, ', '.join('%.1f' % t for t in times))}
@@ -323,15 +405,52 @@ def other_configs(a, local_rank, steps=10, warmup=5):
                     'loss' if not forward_only else 'logit_sum': round(float(last.item()), 5),
                     'wall_s_incl_build': round(time.perf_counter() - t_build, 1)})
         gf = GF_PER_CLIP_FWD_BWD.get(frames) if (size == 224 and depth == 12 and not forward_only) else None
+        if (frames, size, depth, forward_only) == (6, 300, 12, False):
+            gf = GF_PER_CLIP_NATIVE
         if gf:
             rec['model_tflops'] = round(batch / dt * gf / 1e3, 1)
+            rec['model_mfma_frac'] = round(batch / dt * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
         res[name] = rec
 
+    # what the reference itself runs (train_CNN.py:1049,1041 defaults -is 300 -bz 16; vivit.py:201 DSTTr(19, 1, 1, 6)): the
+    # only geometry whose parity is pinned DIRECTLY by reference goldens (G5 / G6); P = 362 tokens per frame
+    leg('native', 16, 6, 300, 12, torch.bfloat16, False, False)
     leg('C4', 32, 16, 224, 12, torch.bfloat16, False, False)
     leg('C5', 64, 8, 224, 12, torch.bfloat16, True, False)
     leg('C1', 1, 4, 96, 2, torch.float32, False, True)
     free()
     return res
+
+
+N1_CACHE = [os.path.join(ROOT, 'gpurun_out', 'istvt_bench_n1.json'), '/tmp/istvt_bench_n1.json']
+
+
+def n1_cache_write(out):
+    """the N = 1 headline (value, ms per step, cpu_baseline) where a later N > 1 run on the same node finds it"""
+    rec = {'value': out['value'], 'unit': out['unit'], 'ms_per_step': out['ms_per_step'], 'workload': out['config']['workload'],
+           'cpu_baseline': out.get('cpu_baseline'), 'written_unix': int(time.time()), 'host': os.uname().nodename}
+    for path in N1_CACHE:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w') as fh:
+                json.dump(rec, fh)
+        except OSError:
+            pass
+
+
+def n1_cache_read():
+    best = None
+    for path in N1_CACHE:
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+            if rec.get('host') == os.uname().nodename and (best is None or rec['written_unix'] > best['written_unix']):
+                best = rec
+        except (OSError, ValueError, KeyError):
+            pass
+    if best is not None:
+        best['age_s'] = int(time.time()) - best['written_unix']
+    return best
 
 
 def config_name(a, world):
@@ -435,14 +554,19 @@ def headline(a, world, rank, local_rank, multi):
     sync()
     t0 = time.perf_counter()
     marks = []
-    for _ in range(a.steps):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]       # one record per step: SURVEY 8(d)'s median
+    evs[0].record()
+    for i in range(a.steps):
         loss = step()
+        evs[i + 1].record()
         marks.append(time.perf_counter())
     # host time to enqueue one step, taken from the first two steps after the sync: later ones include waiting for
     # room in the launch queue (the GPU is ~2.5 steps behind by then)
     t_enq = (marks[min(1, len(marks) - 1)] - t0) / min(2, len(marks))
     sync()
     elapsed = time.perf_counter() - t0
+    ev_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps))
+    ev_median = ev_ms[len(ev_ms) // 2] if len(ev_ms) % 2 else 0.5 * (ev_ms[len(ev_ms) // 2 - 1] + ev_ms[len(ev_ms) // 2])
     per_rank = None
     if multi:
         # every rank's own time for the K steps (the first N > 1 run on real hardware should diagnose itself: a slow rank,
@@ -492,6 +616,32 @@ def headline(a, world, rank, local_rank, multi):
             bucket.disable_early_all_reduce()
         else:
             bucket.enable_early_all_reduce(next(i for i, (n, _) in enumerate(live_named) if n.startswith('vit.')))
+
+    # ---- N > 1: the same K steps on every rank with NO collective (what each GPU does alone, in this very job: same
+    # clocks, same host load), so that one line separates "the GPUs are slower together" from "the all-reduce costs".
+    alone = None
+    if multi and not a.eval:
+        was_early = bucket._early is not None
+        first_vit = next(i for i, (n, _) in enumerate(live_named) if n.startswith('vit.'))
+        bucket.disable_early_all_reduce()
+        step(reduce=False); step(reduce=False)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step(reduce=False)
+        torch.cuda.synchronize(dev)
+        mine_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        all_ = [torch.zeros_like(mine_) for _ in range(world)]
+        dist.all_gather(all_, mine_)
+        ts = [float(t.item()) for t in all_]
+        alone = {'per_rank_ms_per_step': [round(t / a.steps * 1e3, 3) for t in ts],
+                 'ms_per_step': round(max(ts) / a.steps * 1e3, 3),
+                 'clips_per_s_if_free': round(world * a.batch * a.steps / max(ts), 3),
+                 'collective_cost_ms_per_step': round((elapsed - max(ts)) / a.steps * 1e3, 3),
+                 'note': 'every rank runs the same K steps without any collective, all ranks at once; headline ms_per_step '
+                         'minus this = what the all-reduce (and its overlap losses) costs per step'}
+        if was_early:
+            bucket.enable_early_all_reduce(first_vit)
 
     # ---- extra field: the same K steps with the opt-in dead-row elimination (identical logits / gradients, fewer FLOPs)
     dre = None
@@ -577,10 +727,16 @@ def headline(a, world, rank, local_rank, multi):
             d[1] += nbytes
             d[2] += flops
             d[3] += 1
+        # spatial attention alone cannot reach the MFMA peak: its arithmetic intensity is P / 2 flop per byte of q, k, v, o
+        # (SURVEY 7.3-2), so its roof is min(MFMA peak, AI x HBM peak) -- 788 TFLOP/s at P = 197
+        p_tok = grid * grid + 1
+        min_roof = min(PEAK_BF16_TFLOPS, p_tok / 2.0 * PEAK_HBM_GBPS / 1e3)
         kern = {k: {'ms_per_step': round(v[0] * 1e3, 3), 'launches': v[3], 'GBps': round(v[1] / v[0] / 1e9, 1),
                     'frac_hbm_peak': round(v[1] / v[0] / 1e9 / PEAK_HBM_GBPS, 3),
                     **({'TFLOPs': round(v[2] / v[0] / 1e12, 2),
-                        'frac_mfma_peak': round(v[2] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4)}      # BASELINE.json: "attn MFMA util %"
+                        'frac_mfma_peak': round(v[2] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4),      # BASELINE.json: "attn MFMA util %"
+                        'min_roof_TFLOPs': round(min_roof, 1),
+                        'frac_of_min_roof': round(v[2] / v[0] / 1e12 / min_roof, 4)}
                        if k.startswith('attn_spatial') else {})}
                 for k, v in agg.items() if v[0] > 0}
         by = {}                                   # rocprof kernel name -> [flops, seconds, launches]
@@ -613,6 +769,13 @@ def headline(a, world, rank, local_rank, multi):
                 'all_gemm': {'tflops': round(tot_f / tot_t / 1e12, 2), 'ms_per_step': round(tot_t * 1e3, 3),
                              'by_kernel': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'ms': round(v[1] * 1e3, 3),
                                                'launches': v[2]} for k, v in by.items()}}}
+        fam = [v for k, v in by.items() if k.startswith('gemm256q_kernel')]
+        if fam:
+            ff_, ft_, fn_ = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
+            # rocprof splits ONE source kernel (the persistent NT GEMM) into a name per template instantiation; together:
+            roof['family'] = {'kernel': 'gemm256q_kernel<*> (all %d instantiations of the persistent NT GEMM)' % len(fam),
+                              'achieved': round(ff_ / ft_ / 1e12, 2), 'frac': round(ff_ / ft_ / 1e12 / peak, 4),
+                              'ms_per_step': round(ft_ * 1e3, 3), 'launches_per_step': fn_}
         # HBM traffic per launch is not measurable from inside the process: it comes from the committed PMC
         # passes over this same command (profiles/pmc/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE)
         pmc = pmc_summary_path()
@@ -665,10 +828,13 @@ def headline(a, world, rank, local_rank, multi):
         # bound.  (Replaying the step as one captured HIP graph was tried: hipGraphLaunch of the 1500-node graph costs
         # the host 35 ms per replay on this ROCm, no better than the eager loop.)
         out['host_enqueue_ms_per_step'] = round(t_enq * 1e3, 3)
+        # hipEvent timing, median -- one event per step on the launch stream inside the timed region (rank 0);
+        # `ms_per_step` / `value` stay the contract's wall clock over exactly K steps, max over ranks
+        out['ms_per_step_event_median'] = round(ev_median, 3)
         out['config']['dead_row_elimination'] = bool(a.dead_row_elimination)
-        # DSTTr reads one row per clip of the final LayerNorm (vivit.py:144-146): only those rows are normalised
-        # (bit-identical, < 0.1 % of the step), unlike dead_row_elimination this is always on
-        out['config']['final_norm_class_rows_only'] = True
+        # the default model normalises every row in the final LayerNorm, as the reference does (vivit.py:100); only the
+        # opt-in dead-row elimination restricts it to the rows DSTTr reads
+        out['config']['final_norm_class_rows_only'] = bool(a.dead_row_elimination)
         out['config']['optimizer'] = ('AdamW' if a.optimizer == 'Adam' else 'SGD(momentum 0.9)') + (' torch' if a.torch_optimizer else ' fused')
         out['config']['lr'] = a.learning_rate
         out['config']['weight_decay'] = a.weight_decay
@@ -685,7 +851,7 @@ def headline(a, world, rank, local_rank, multi):
                                   'collectives_per_step': 1 if (a.no_early_allreduce or bool(schedules and schedules.get('single_blocking_allreduce', {}).get('headline'))) else 2,
                                   'headline_rule': 'the faster of the two schedules, each timed over the same K steps (max over ranks); --keep-schedule / --no-early-allreduce pin one',
                                   'cu_reserve_during_early_allreduce': bucket.cu_reserve,
-                                  'schedules': schedules}
+                                  'schedules': schedules, 'without_collectives': alone}
         ms = torch.cuda.memory_stats(dev)
         out['allocator'] = {'reserved_GB': round(ms.get('reserved_bytes.all.peak', 0) / 2**30, 2),
                             'device_allocs': ms.get('num_device_alloc', 0), 'device_frees': ms.get('num_device_free', 0),
@@ -700,8 +866,9 @@ def headline(a, world, rank, local_rank, multi):
 
 def main():
     a = parse()
-    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (a.gpus > 1 or a.self_launch) and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(a))
+    _import_torch()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -738,12 +905,23 @@ def main():
     if rank == 0:
         if pinned is not None and 'distributed' in out:
             out['distributed']['cores_per_rank'] = len(pinned)
+        if os.environ.get('ISTVT_BENCH_LAUNCHER'):
+            out['launcher'] = json.loads(os.environ['ISTVT_BENCH_LAUNCHER'])        # what the self-launching parent saw
+        elif 'WORLD_SIZE' in os.environ:
+            out['launcher'] = {'self_launched': False, 'note': 'ranks started by the caller (torch.distributed.run)'}
         default_c2 = (a.batch, a.frames, a.size, a.depth, a.dtype, bool(a.attn_fp8)) == (32, 8, 224, 12, 'bf16', False)
         if world == 1 and default_c2 and not (a.eval or a.no_other_configs or a.rccl_rehearsal):
             # BASELINE.json's other single-GPU configurations, short legs after the headline (its model is freed)
             out['other_configs'] = other_configs(a, local_rank)
         if world == 1 and not a.no_cpu_baseline and not a.eval:
             out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
+        if world == 1 and default_c2 and not (a.eval or a.rccl_rehearsal or a.dead_row_elimination):
+            n1_cache_write(out)
+        if world > 1:
+            # cpu_baseline is measured at N = 1 only (bounded sample on rank 0); the N > 1 line carries the newest N = 1
+            # record of this host, if a run left one, so SCALE can be cross-checked against BENCH from one line
+            out['n1_reference'] = n1_cache_read() or {'note': 'no N=1 run of this host on record (run `python bench.py` first); '
+                                                             'see distributed.without_collectives for the same-job figure'}
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

@@ -63,7 +63,12 @@ typedef void* istvt_stream_t; /* hipStream_t */
  *           bit 1 (bfloat16 forward on the persistent NT kernel only, -3 otherwise): A is TWO planes of M rows, the
  *           second directly behind the first (A + M * lda elements); output columns at or past 64 * (flags >> 16), a
  *           multiple of 256, take their rows from the second plane.  TemporalResidualAttention (module.py:193-196): q | k
- *           are projections of the frame-differenced LayerNorm output, v of the plain one -- one 728 -> 1536 GEMM. */
+ *           are projections of the frame-differenced LayerNorm output, v of the plain one -- one 728 -> 1536 GEMM.
+ *           bits 8..15: CUs, in units of 8 (at most 24 = 192 CUs, -3 otherwise), that a launch of the persistent NT kernel
+ *           leaves free: set while a collective's kernels occupy CUs (the data-parallel gradient all-reduce that overlaps
+ *           the stem backward, train_CNN.py:185-186 -> parallel.GradBucket), so that every persistent workgroup is resident
+ *           at once instead of queueing behind a whole tile list.  An argument of each launch: the library keeps no state
+ *           (results are bit-identical for every value: one workgroup computes an output tile in one fixed order). */
 int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long ldb, int b_kc, void* C, long ldc, int M, int N,
                int K, const float* bias, const void* residual, long ldr, void* C2, int epi, int out_mode, int splitk,
                float alpha, double* col_sum, double* col_sumsq, int flags, int dtype, istvt_stream_t stream);
@@ -82,11 +87,6 @@ int istvt_wgrad_group(int count, const void* const* dy, const long* lddy, const 
                       float* const* out, const int* N, const int* K, int M, int splits, float* ws, long ws_elems,
                       istvt_stream_t stream);
 int istvt_wgrad_group_splits(int count, const int* N, const int* K, int M);
-/* CUs the persistent NT GEMM launches that follow leave free (0 = none, the default; returns the previous value): set
- * while a collective's kernels occupy CUs (the data-parallel gradient all-reduce that overlaps the stem backward,
- * train_CNN.py:185-186 -> parallel.GradBucket), so that every persistent workgroup is resident at once instead of
- * queueing behind a whole tile list.  Host-side state of the calling process, read at launch. */
-int istvt_set_cu_reserve(int n);
 
 /* ---- LayerNorm (module.py:15-21 PreNorm; vivit.py:89,128) ---------------------------------- */
 int istvt_layernorm_fwd(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,

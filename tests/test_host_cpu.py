@@ -304,10 +304,43 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert out['plumbing_only'] is True and out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1
     assert out['distributed']['ranks'] == 2 and out['distributed']['backend'] == 'gloo'
     assert len(out['distributed']['per_rank_s']) == 2
+    # the parent counts devices without torch / HIP (environment lists, else sysfs) and never has the
+    # HIP runtime mapped when it spawns the ranks
+    la = out['launcher']
+    assert la['self_launched'] is True and la['parent_imported_torch'] is False and la['parent_mapped_hip_runtime'] is False
     # a failing rank must fail the parent: an unknown flag makes every rank exit 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--plumbing-only', '--no-such-flag'],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0
+
+
+def test_bench_parent_counts_gpus_without_the_runtime(monkeypatch):
+    """bench.visible_gpus(): *_VISIBLE_DEVICES lists (the smallest wins) capped by the KFD topology, no torch, no HIP; and
+    `grep torch.cuda` finds nothing in bench.py before self_launch returns (the parent's whole code path)."""
+    import importlib
+    bench = importlib.import_module('bench')
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    n0, src0 = bench.visible_gpus()
+    assert (n0 is None) or (isinstance(n0, int) and n0 >= 0 and 'kfd' in src0)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    n, src = bench.visible_gpus()
+    assert src == 'HIP_VISIBLE_DEVICES' and n == (3 if n0 is None else min(3, n0))
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '0')
+    n, src = bench.visible_gpus()
+    assert src == 'ROCR_VISIBLE_DEVICES' and n == (1 if n0 is None else min(1, n0))
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert bench.visible_gpus()[0] == 0
+    src_text = open(os.path.join(ROOT, 'bench.py')).read()
+    parent = src_text[:src_text.index('def pin_rank(')]            # parse(), visible_gpus(), self_launch()
+    assert 'torch.cuda' not in parent and 'import torch' not in parent.replace('import torch as _t', '').replace(
+        'import torch.distributed as _d', '')
+    # too few devices: refused by the parent, with the source of the count (no rank is started)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'ISTVT_BENCH_REHEARSAL')}
+    env['HIP_VISIBLE_DEVICES'] = '0'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'only' in (r.stderr + r.stdout) and 'GPU(s) visible' in (r.stderr + r.stdout)
 
 
 def test_data_parallel_wrapper_is_refused_with_the_way_out(pkg):
@@ -411,11 +444,25 @@ def test_bench_accepts_the_reference_training_flags(monkeypatch):
         parse('--gpus', '4', '-d', '0,1')
 
 
-def test_cu_reserve_entry_point(pkg):
-    """istvt_set_cu_reserve is host-side state of the library: returns the previous value, refuses nonsense (no GPU needed)"""
-    from istvt_amd import _lib
+def test_cu_reserve_is_a_launch_argument_not_library_state(pkg):
+    """the entry points hold no global mutable state.  The CUs a persistent GEMM launch leaves to a collective
+    travel in istvt_gemm's flags (bits 8..15, units of 8 CUs); the library exports no setter, ops keeps the value per
+    device on the Python side and hands back the previous one for restoring (no GPU needed: the range check precedes
+    every HIP call)."""
+    import ctypes
+    from istvt_amd import _lib, ops
     lib = _lib.lib()
-    assert lib.istvt_set_cu_reserve(32) == 0
-    assert lib.istvt_set_cu_reserve(0) == 32
-    assert lib.istvt_set_cu_reserve(-1) < 0 and lib.istvt_set_cu_reserve(10000) < 0
-    assert lib.istvt_set_cu_reserve(0) == 0
+    assert not hasattr(ctypes.CDLL(_lib.LIB_PATH), 'istvt_set_cu_reserve')
+    assert ops.set_cu_reserve(32, 0) == 0 and ops.get_cu_reserve(0) == 32
+    assert ops.set_cu_reserve(100, 0) == 32 and ops.get_cu_reserve(0) == 104        # whole XCD-multiples of 8
+    assert ops.get_cu_reserve(1) == 0                                               # per device
+    assert ops.set_cu_reserve(0, 0) == 104
+    for bad in (-1, 193, 10000):
+        with pytest.raises(RuntimeError):
+            ops.set_cu_reserve(bad, 0)
+    # 25 units = 200 CUs: refused by the entry point itself
+    rc = lib.istvt_gemm(None, 64, 1, None, 64, 1, None, 256, 256, 256, 64, None, None, 0, None, 0, 0, 1, 1.0, None, None,
+                        25 << 8, 1, None)
+    assert rc == -3
+
+

@@ -799,7 +799,7 @@ def test_bench_two_rank_path_rehearsal():
     assert abs(out['ms_per_step'] - sch[heads[0]]['ms_per_step']) < 1e-2
     assert all(len(v['per_rank_ms_per_step']) == 2 and v['ms_per_step'] > 0 for v in sch.values())
     assert out['distributed']['collectives_per_step'] == (1 if heads[0] == 'single_blocking_allreduce' else 2)
-    assert out['config']['final_norm_class_rows_only'] is True
+    assert out['config']['final_norm_class_rows_only'] is False         # the default model runs what the reference runs
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -879,6 +879,38 @@ def test_bench_gpus_n_self_launch_rehearsal():
     assert out['n_gpus'] == 2 and out['distributed']['ranks'] == 2 and out['distributed']['backend'] == 'gloo'
     assert out['value'] > 0 and out['scaling'] == 'weak'
     assert out['with_host_boundary']['ms_per_step'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_real_self_launch_parent_on_this_box():
+    """the NON-rehearsal branch of bench.self_launch, end to end on real hardware -- the parent counts
+    the box's GPUs from the environment / KFD sysfs (no torch, no HIP runtime mapped: it reports both), spawns
+    `python -m torch.distributed.run` as a child, and the rank it starts initialises RCCL ("nccl") on its GPU and runs
+    every collective of the data-parallel step (--rccl-rehearsal: a process group of one rank).  `--self-launch` takes the
+    launcher path that `--gpus N > 1` takes, with the one GPU this box has.  Also: asking for more GPUs than the box has is
+    refused by the parent before any rank starts."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'ISTVT_BENCH_REHEARSAL')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--self-launch', '--gpus', '1', '--rccl-rehearsal', '--steps', '2',
+           '--warmup', '1', '--batch', '2', '--frames', '4', '--size', '96', '--depth', '2', '--no-cpu-baseline',
+           '--no-kernel-profile', '--no-dre-extra', '--no-host-boundary']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    la = out['launcher']
+    assert la['self_launched'] is True and la['parent_imported_torch'] is False and la['parent_mapped_hip_runtime'] is False
+    assert isinstance(la['visible_gpus'], int) and la['visible_gpus'] >= 1, la
+    assert out['distributed']['backend'] == 'nccl' and out['distributed']['ranks'] == 1 and out['value'] > 0
+    assert out['distributed']['without_collectives']['ms_per_step'] > 0
+    # more GPUs than the box has: the parent says so (and what it counted from) and starts nothing
+    n = la['visible_gpus']
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1), '--steps', '1'],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'GPU(s) visible' in (r.stdout + r.stderr)
 
 
 @pytest.mark.gpu
