@@ -93,13 +93,18 @@ class LayerNormDiffFn(Function):
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.set_materialize_grads(False)
         ctx.sink = sink
-        ctx.mark_non_differentiable(yd)
         y, yd = y.view(*x.shape), yd.view(*x.shape)
+        ctx.mark_non_differentiable(yd)         # the tensor that is RETURNED (a view made after the mark would not carry it)
         return (y, yd, x.view_as(x)) if fork else (y, yd)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, _dyd=None, dres=None):
+        if _dyd is not None:
+            # the difference plane is an operand, not a differentiable output: a consumer that sends a gradient into it
+            # would have it dropped silently
+            raise RuntimeError('LayerNormDiffFn: the frame-difference plane carries no gradient of its own (its consumer '
+                               'returns the gradient of the whole difference-project-attend chain through y)')
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         dcol = ctx.sink.buffer() if ctx.sink is not None else None
         if dy is None:

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from istvt_amd import functional as Fn
+from istvt_amd import ops
 
 
 def _frames(n, hw, what):
@@ -151,6 +152,12 @@ class TemporalResidualAttention(nn.Module):
             return None
         frames = x.shape[1] // hw
         if frames > 32 or self.dim_head not in (32, 64) or x.shape[0] * x.shape[1] < 256:
+            return None
+        # the kernel-side preconditions of this path, mirrored (csrc/gemm.hip q_ok + a_sel): the two-plane A operand of
+        # the persistent NT GEMM is addressed with 32-bit byte offsets (both planes below 2 GiB), K is a multiple of 8 and
+        # at least 32; otherwise the caller falls back to the one-plane path (diff = 1), which every kernel takes
+        rows, d = x.shape[0] * x.shape[1], x.shape[2]
+        if d % 8 or d < 32 or 2 * rows * ops.pad_ld(d) * 2 >= 0x7fffffff or 3 * inner * ops.pad_ld(d) * 2 >= 0x7fffffff:
             return None
         return (x.shape[0], frames, hw)
 

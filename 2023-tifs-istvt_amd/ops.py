@@ -119,6 +119,42 @@ def _versions(ws) -> tuple:
     return tuple(w._version for w in ws) + (_wepoch[0],)
 
 
+def _holders(t: Tensor) -> tuple:
+    """(Python references, C++ references to the TensorImpl -- autograd SavedVariables --, tensors sharing the storage --
+    views and slices) of `t`, each including what THIS call adds.  Only differences between two calls made the same way
+    mean anything: _operand_holders() is the one place that calls it."""
+    return (sys.getrefcount(t), t._use_count(), torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+
+
+def _operand_holders(key) -> tuple:
+    _refs, out, wt = _operands[key]
+    return _holders(out) + _holders(wt)
+
+
+def _idle_holder_counts(view: bool) -> tuple:
+    """what _operand_holders() returns for an operand pair that NOTHING but the two caches holds: measured, not assumed --
+    a throw-away pair is put through the same dict / tuple structure and the same call (so another Python version's
+    reference accounting, or a refactor of the cache entries, moves the baseline and the check together)."""
+    if view not in _idle_counts:
+        saved = (dict(_operands), dict(_wcache))
+        try:
+            key = ('calibration', view)
+            mk = (lambda: torch.empty((2, 16))[:, :8]) if view else (lambda: torch.empty((2, 8)))
+            out, wt = mk(), mk()
+            _operands[key] = ((), out, wt)
+            _wcache[key] = (None, None, out)
+            _wcache[(id(out), 'T')] = (None, 0, wt)
+            del out, wt
+            _idle_counts[view] = _operand_holders(key)
+        finally:
+            _operands.clear(); _operands.update(saved[0])
+            _wcache.clear(); _wcache.update(saved[1])
+    return _idle_counts[view]
+
+
+_idle_counts: dict = {}
+
+
 def refresh_stale_operands() -> int:
     """Re-cast, in one grouped launch (istvt_cast_transpose_group), the bf16 operand copies (W and W^T) of every weight
     that changed since they were made -- i.e. of all of them after an optimizer step.  The models call this at the start
@@ -138,14 +174,20 @@ def refresh_stale_operands() -> int:
             # live autograd graph that saved them (ctx attributes or save_for_backward of RepChainFn / StemFn / LinearFn:
             # forward A -> optimizer step -> forward B -> backward A) must still find forward A's weights: those copies are
             # left alone -- dropped from the caches, so the next use makes fresh ones -- and die with the graph.
-            # (references: out = _operands tuple + _wcache tuple + `out` here + getrefcount's argument = 4; wt likewise
-            #  with its own _wcache entry; _use_count() counts C++ holders such as SavedVariable.)
-            if (sys.getrefcount(out) > 4 or sys.getrefcount(wt) > 4 or out._use_count() > 1 or wt._use_count() > 1):
+            # Holders are counted three ways (_holders: Python references, C++ references such as SavedVariable, tensors
+            # sharing the storage such as views / slices) and compared with the counts of an operand pair that only the
+            # caches hold, measured once through the same structures (_idle_holder_counts).
+            del out, wt, hit
+            idle = (_idle_holder_counts(_operands[key][1]._base is not None)[:3]
+                    + _idle_holder_counts(_operands[key][2]._base is not None)[3:])
+            if any(a > b for a, b in zip(_operand_holders(key), idle)):
+                _refs, out, _wt = _operands[key]
                 _operands.pop(key, None)
                 _wcache.pop(key, None)
                 _wcache.pop((id(out), 'T'), None)
                 continue
-            todo.append((key, ws, out, wt, ver, hit))
+            _refs, out, wt = _operands[key]
+            todo.append((key, ws, out, wt, ver, _wcache[key]))
     if not todo:
         return 0
     srcs, ins, ldi, outs, ldo, outts, ldt, Rs, Cs = [], [], [], [], [], [], [], [], []

@@ -514,6 +514,106 @@ def g9_dualnet_halves():
     save('G9_dualnet_halves', **out)
 
 
+def load_cond(module: nn.Module, prefix: str = ''):
+    sd = module.state_dict()
+    vals = recipe.cond_fill_state_dict(sd, prefix)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+
+
+class _ScoreProbe:
+    """max |score| and mean softmax entropy (relative to log F) of every TemporalResidualAttention, recomputed from the
+    output of its to_qk Linear (forward hook): says in the fixture itself that no temporal softmax is saturated"""
+
+    def __init__(self, model, tokens_per_frame):
+        self.rows = []
+        self.p = tokens_per_frame
+        for name, m in model.named_modules():
+            if isinstance(m, ref_module.TemporalResidualAttention):
+                m.to_qk.register_forward_hook(self._hook(name, m.heads, m.scale))
+
+    def _hook(self, name, heads, scale):
+        def fn(_mod, _inp, out):
+            with torch.no_grad():
+                q, k = out.double().chunk(2, dim=-1)
+                b, n, hd = q.shape
+                f = n // self.p
+                q = q.view(b, f, self.p, heads, hd // heads).permute(0, 3, 2, 1, 4)
+                k = k.view(b, f, self.p, heads, hd // heads).permute(0, 3, 2, 1, 4)
+                s = torch.einsum('...id,...jd->...ij', q, k) * scale
+                pr = s.softmax(-1)
+                ent = -(pr * pr.clamp_min(1e-300).log()).sum(-1).mean() / np.log(f)
+                self.rows.append((name, float(s.abs().max()), float(ent)))
+        return fn
+
+    def summary(self):
+        return (np.array([r[0] for r in self.rows]), np.array([r[1] for r in self.rows], dtype=np.float64),
+                np.array([r[2] for r in self.rows], dtype=np.float64))
+
+
+def _capture_grads(model, out, suffix, store_sub):
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        out['gnorm%s.%s' % (suffix, k)] = npy(p.grad.double().norm())
+        if store_sub:
+            g = p.grad.reshape(-1)
+            idx = torch.from_numpy(recipe.grad_subsample_index(g.numel()))
+            out['gsub64.' + k] = npy(g[idx]).astype(np.float32)
+
+
+def g5c_native_conditioned():
+    """G5 for bfloat16 gradient parity: the reference XceptionVidTr() on a clip of CORRELATED frames
+    (base + 0.3 x noise per frame: what a face video is, and the hard case for the frame-differenced q / k operands) with
+    the well-conditioned recipe (recipe.cond_param_value): logit, loss, the norm of every live gradient in float32 AND
+    float64, and 4096 evenly spaced entries of every float64 gradient tensor (cosine / direction checks)."""
+    out = {}
+    x32 = t(recipe.correlated_frames('g5c.x', (1, 6, 3, 300, 300)))
+    for dt, suffix in ((torch.float64, '64'), (torch.float32, '')):
+        model = ref_vivit.XceptionVidTr()
+        load_cond(model, '')
+        model = model.to(dt).train()
+        probe = _ScoreProbe(model, 362) if dt == torch.float64 else None
+        logits = model(x32.to(dt))
+        loss = nn.BCEWithLogitsLoss()(logits.view(-1), torch.ones(1, dtype=dt))
+        loss.backward()
+        out['logits' + suffix] = npy(logits)
+        out['loss' + suffix] = npy(loss)
+        _capture_grads(model, out, suffix, store_sub=(dt == torch.float64))
+        if probe is not None:
+            out['probe.names'], out['probe.max_abs_score'], out['probe.rel_entropy'] = probe.summary()
+            print('temporal scores: max |s| %.2f, min relative entropy %.3f' % (out['probe.max_abs_score'].max(),
+                                                                                out['probe.rel_entropy'].min()))
+        if dt == torch.float32:
+            out['live_param_names'] = np.array([k for k, p in model.named_parameters() if p.grad is not None])
+    save('G5c_native_conditioned', **out)
+
+
+def g6c_fullwidth_conditioned():
+    """G6 likewise: DSTTr(19, 1, 1, 8, depth=2) at full width (dim 728) on correlated feature frames, well-conditioned
+    recipe; logit, input-gradient subsample, every parameter-gradient norm (f32, f64) + float64 subsamples."""
+    out = {}
+    x32 = recipe.correlated_frames('g6c.x', (1, 8, 728, 19, 19))
+    for dt, suffix in ((torch.float64, '64'), (torch.float32, '')):
+        mod = ref_vivit.DSTTr(19, 1, 1, 8, depth=2)
+        load_cond(mod, 'vit.')
+        mod = mod.to(dt)
+        probe = _ScoreProbe(mod, 362) if dt == torch.float64 else None
+        x = t(x32).to(dt).requires_grad_(True)
+        y = mod(x)
+        y.sum().backward()
+        out['logits' + suffix] = npy(y)
+        out['dx_norm' + suffix] = npy(x.grad.double().norm())
+        _capture_grads(mod, out, suffix, store_sub=(dt == torch.float64))
+        if dt == torch.float64:
+            g = x.grad.reshape(-1)
+            out['dxsub64'] = npy(g[torch.from_numpy(recipe.grad_subsample_index(g.numel(), 16384))]).astype(np.float32)
+            out['probe.names'], out['probe.max_abs_score'], out['probe.rel_entropy'] = probe.summary()
+            print('temporal scores: max |s| %.2f, min relative entropy %.3f' % (out['probe.max_abs_score'].max(),
+                                                                                out['probe.rel_entropy'].min()))
+    save('G6c_fullwidth_conditioned', **out)
+
+
+ALL.update({'G5c': g5c_native_conditioned, 'G6c': g6c_fullwidth_conditioned})
 ALL.update({'G1b': g1b_stem224, 'G2b': g2b_modules_f17, 'G4b': g4b_dsttr_t16, 'G5b': g5b_native_fp64, 'G7': g7_xception,
             'G8': g8_siblings, 'G9': g9_dualnet_halves})
 

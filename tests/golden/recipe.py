@@ -86,3 +86,40 @@ def rand_fill_state_dict(sd: dict, prefix: str = '') -> dict:
 
 def rand_input_value(name: str, shape, scale: float = 1.0) -> np.ndarray:
     return (scale * _rng('input:' + name).standard_normal(tuple(shape))).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Well-conditioned recipe (round 5, goldens G5c / G6c): the pseudo-random recipe with the attention score scale brought
+# down so that no softmax saturates -- the point of these fixtures is to pin bfloat16 GRADIENTS against the reference,
+# and one bf16 rounding of a score of ~50 (the sin-wave recipe of G5 / G6) moves a probability by a factor.
+#   * `to_qk.weight` x 0.7 (temporal scores: q, k are projections of frame DIFFERENCES, variance ~2 for independent frames)
+#   * the q | k rows (first two thirds) of `to_qkv.weight` x 0.7 (spatial scores)
+# make_golden.py measures max |score| and the mean softmax entropy of every temporal block and stores them in the fixture.
+def cond_param_value(name: str, shape) -> np.ndarray:
+    v = rand_param_value(name, shape)
+    leaf2 = '.'.join(name.split('.')[-2:])
+    if leaf2 == 'to_qk.weight':
+        v = (v * np.float32(0.7)).astype(np.float32)
+    elif leaf2 == 'to_qkv.weight':
+        n = shape[0] // 3 * 2
+        v = v.copy()
+        v[:n] *= np.float32(0.7)
+    return v
+
+
+def cond_fill_state_dict(sd: dict, prefix: str = '') -> dict:
+    return {k: cond_param_value(prefix + k, tuple(v.shape)) for k, v in sd.items()}
+
+
+def correlated_frames(name: str, shape, frame_axis: int = 1, change: float = 0.3) -> np.ndarray:
+    """frames of a clip as a face video has them: one base frame + `change` x independent noise per frame (float32)"""
+    shape = tuple(shape)
+    base_shape = shape[:frame_axis] + (1,) + shape[frame_axis + 1:]
+    base = _rng('input:' + name + ':base').standard_normal(base_shape)
+    noise = _rng('input:' + name + ':noise').standard_normal(shape)
+    return (base + change * noise).astype(np.float32)
+
+
+def grad_subsample_index(n: int, keep: int = 4096) -> np.ndarray:
+    """the (at most `keep`) evenly spaced flat positions at which G5c / G6c store a gradient tensor"""
+    return np.linspace(0, n - 1, min(n, keep)).astype(np.int64)

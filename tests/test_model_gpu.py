@@ -434,7 +434,7 @@ def test_g5_native_bf16_vs_reference_golden(golden_dir):
     loss.backward()
     print('G5 bf16: logit %.5f (reference %.5f), loss %.5f (reference %.5f)'
           % (float(logits), float(g['logits'].reshape(-1)[0]), float(loss), float(g['loss'])))
-    assert abs(float(logits) - float(g['logits'].reshape(-1)[0])) <= 0.1 * max(1.0, abs(float(g['logits'].reshape(-1)[0])))
+    assert abs(float(logits) - float(g['logits'].reshape(-1)[0])) <= BF16_LOGIT_TOL * max(1.0, abs(float(g['logits'].reshape(-1)[0])))
     named = dict(model.named_parameters())
     live = [str(s) for s in g['live_param_names']]
     assert sorted(k for k, p in named.items() if p.grad is not None) == sorted(live)
@@ -939,3 +939,111 @@ def test_bench_rccl_one_rank_rehearsal():
     assert d['backend'] == 'nccl' and d['ranks'] == 1 and d['rccl_rehearsal'] and len(d['per_rank_ms_per_step']) == 1
     assert rccl['config']['early_allreduce'] and rccl['n_gpus'] == 1
     assert rccl['config']['loss'] == plain['config']['loss']
+
+
+# ------------------------------------------------------------------------------------------------------------------ round 5
+# bfloat16 GRADIENTS against vectors the REFERENCE produced.  G5c / G6c: the reference's own modules on
+# correlated frames with the well-conditioned recipe (no saturated softmax: the fixture carries max |score| <= 3 and the
+# softmax entropies), float32 and float64 runs, the norm of every live gradient and 4096 evenly spaced entries of each
+# float64 gradient.  The float32 HIP path is held to SURVEY 8(c)'s 1e-2 on the transformer's gradient norms (2e-2 only for
+# the stem, whose ReLU / arg-max decisions can flip under another summation order); the bfloat16 path -- what bench.py
+# times -- to a direction (cosine) and a norm ratio on EVERY live tensor, the temporal block's to_qk / to_v included.
+def _cond_state(model, prefix=''):
+    sd = model.state_dict()
+    model.load_state_dict({k: torch.from_numpy(recipe.cond_param_value(prefix + k, tuple(v.shape))) for k, v in sd.items()})
+    return model.cuda().train()
+
+
+def _sub(t):
+    flat = t.detach().reshape(-1)
+    return flat[torch.from_numpy(recipe.grad_subsample_index(flat.numel())).to(flat.device)].double().cpu()
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), torch.as_tensor(np.asarray(b), dtype=torch.float64).reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+BF16_GRAD_COS = 0.97            # every live tensor
+BF16_GRAD_NORM = 0.15           # |norm ratio - 1|
+
+
+def _grad_report(named, g, keys, prefix=''):
+    rows = []
+    for k in keys:
+        gr = named[k].grad
+        rows.append((k, _cos(_sub(gr), g['gsub64.' + prefix + k]), float(gr.double().norm()) / float(g['gnorm64.' + prefix + k])))
+    return rows
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_g6c_fullwidth_conditioned_hip(golden_dir, dtype):
+    """DSTTr(19, 1, 1, 8, depth=2) at full width vs the reference capture G6c"""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network.vivit import vivit as V
+    g = np.load(os.path.join(golden_dir, 'G6c_fullwidth_conditioned.npz'))
+    mod = _cond_state(V.DSTTr(19, 1, 1, 8, depth=2, compute_dtype=dtype), 'vit.')
+    x = torch.from_numpy(recipe.correlated_frames('g6c.x', (1, 8, 728, 19, 19))).cuda().requires_grad_(True)
+    y = mod(x)
+    y.sum().backward()
+    named = dict(mod.named_parameters())
+    rows = _grad_report(named, g, list(named))
+    flat = x.grad.reshape(-1)
+    dxs = flat[torch.from_numpy(recipe.grad_subsample_index(flat.numel(), 16384)).cuda()].double().cpu()
+    dx_cos, dx_ratio = _cos(dxs, g['dxsub64']), float(x.grad.double().norm()) / float(g['dx_norm64'])
+    worst_c, worst_n = min(rows, key=lambda r: r[1]), max(rows, key=lambda r: abs(r[2] - 1))
+    print('G6c %s: logit %.6f (reference f64 %.6f); worst cosine %s, worst norm ratio %s; dx cos %.5f ratio %.4f'
+          % (dtype, float(y), float(g['logits64']), worst_c, worst_n, dx_cos, dx_ratio))
+    if dtype == torch.float32:
+        assert relerr(y, g['logits64']) < 1e-4
+        for k, c, r in rows:
+            assert abs(r - 1) < 1e-3 and c > 0.99999, (k, c, r)
+        assert abs(dx_ratio - 1) < 1e-3 and dx_cos > 0.99999
+    else:
+        assert abs(float(y) - float(g['logits64'])) <= BF16_LOGIT_TOL * max(1.0, abs(float(g['logits64'])))
+        for k, c, r in rows:
+            assert c > BF16_GRAD_COS and abs(r - 1) < BF16_GRAD_NORM, (k, c, r)
+        assert dx_cos > BF16_GRAD_COS and abs(dx_ratio - 1) < BF16_GRAD_NORM
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_g5c_native_conditioned_hip(golden_dir, dtype):
+    """the reference-native model (T=6, 300^2, depth 12) vs the reference capture G5c: logit, loss, every live gradient"""
+    XceptionVidTr, _ = _load()
+    g = np.load(os.path.join(golden_dir, 'G5c_native_conditioned.npz'))
+    model = _cond_state(XceptionVidTr(compute_dtype=dtype))
+    x = torch.from_numpy(recipe.correlated_frames('g5c.x', (1, 6, 3, 300, 300))).cuda()
+    logits = model(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits.view(-1), torch.ones(1, device='cuda'))
+    loss.backward()
+    live = [str(s) for s in g['live_param_names']]
+    named = dict(model.named_parameters())
+    assert sorted(k for k, p in named.items() if p.grad is not None) == sorted(live)
+    rows = _grad_report(named, g, live)
+    vit = [r for r in rows if r[0].startswith('vit.')]
+    xc = [r for r in rows if r[0].startswith('xcep.')]
+    for name, part in (('vit', vit), ('xcep', xc)):
+        print('G5c %s %s: worst cosine %s; worst norm ratio %s; median |ratio - 1| %.2e'
+              % (dtype, name, min(part, key=lambda r: r[1]), max(part, key=lambda r: abs(r[2] - 1)),
+                 sorted(abs(r[2] - 1) for r in part)[len(part) // 2]))
+    print('G5c %s: logit %.6f loss %.6f (reference f64 %.6f %.6f)' % (dtype, float(logits), float(loss), float(g['logits64']), float(g['loss64'])))
+    if dtype == torch.float32:
+        assert relerr(logits, g['logits64']) < 1e-3 and relerr(loss, g['loss64']) < 1e-3
+        for k, c, r in vit:
+            assert abs(r - 1) < 1e-2 and c > 0.9999, (k, c, r)           # SURVEY 8(c): gradient norms rtol 1e-2
+        for k, c, r in xc:
+            assert abs(r - 1) < 2e-2 and c > 0.999, (k, c, r)            # stem: flipped ReLU / arg-max decisions (module docstring)
+    else:
+        assert abs(float(logits) - float(g['logits64'])) <= BF16_LOGIT_TOL * max(1.0, abs(float(g['logits64'])))
+        assert abs(float(loss) - float(g['loss64'])) <= BF16_LOGIT_TOL
+        for k, c, r in vit:
+            assert c > BF16_GRAD_COS and abs(r - 1) < BF16_GRAD_NORM, (k, c, r)
+        # the stem at ONE clip (BatchNorm over 6 correlated frames, six bf16-rounded conv + BN layers): bounds from the
+        # measured values, see DESIGN.md section 4
+        for k, c, r in xc:
+            assert c > BF16_STEM_COS and abs(r - 1) < BF16_STEM_NORM, (k, c, r)
+
+
+BF16_STEM_COS = 0.90
+BF16_STEM_NORM = 0.25

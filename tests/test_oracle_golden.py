@@ -420,3 +420,70 @@ def test_g8_siblings(golden_dir, name, dtype):
         assert relerr(v.grad.norm(), g[tag + 'gnorm.' + k]) < (1e-9 if f64 else 1e-4), k
         if not f64:
             assert relerr(v.grad.reshape(-1)[:4096], g[tag + 'grad.' + k]) < 2e-4, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 5: well-conditioned captures for bfloat16 GRADIENT parity -- G5c (the native model) and G6c
+# (full-width DSTTr, depth 2): correlated frames, no saturated softmax (the fixtures carry the measured max |score| and
+# softmax entropy of every temporal block), every live gradient's norm in float32 and float64 and 4096 evenly spaced
+# entries of the float64 gradient.  Here: the oracle reproduces them (the GPU tests hold the HIP path to them).
+# ------------------------------------------------------------------------------------------------------------------
+def cond_params(shapes, prefix, dtype=torch.float32):
+    return {k: torch.from_numpy(recipe.cond_param_value(prefix + k, s)).to(dtype if len(s) or 'num_batches' not in k else torch.long)
+            for k, s in shapes.items()}
+
+
+def subsample(t):
+    flat = t.detach().reshape(-1)
+    return flat[torch.from_numpy(recipe.grad_subsample_index(flat.numel()))]
+
+
+def cosine(a, b):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64).reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+def test_g5c_fixture_is_well_conditioned(golden_dir):
+    for name in ('G5c_native_conditioned', 'G6c_fullwidth_conditioned'):
+        g = load(golden_dir, name)
+        assert float(g['probe.max_abs_score'].max()) < 3.5 and float(g['probe.rel_entropy'].min()) > 0.85, name
+        # ... and so the reference's own float32 run agrees with its float64 run on every gradient norm to 2e-4
+        for k in g.files:
+            if k.startswith('gnorm64.'):
+                assert relerr(g['gnorm.' + k[8:]], g[k]) < 2e-4, k
+
+
+def test_g6c_fullwidth_conditioned(golden_dir):
+    g = load(golden_dir, 'G6c_fullwidth_conditioned')
+    shapes = R.dsttr_param_shapes(8, 19, depth=2)
+    p = R.with_grad(cond_params(shapes, 'vit.'))
+    x = torch.from_numpy(recipe.correlated_frames('g6c.x', (1, 8, 728, 19, 19))).requires_grad_(True)
+    y = R.dsttr_forward(p, x, depth=2)
+    y.sum().backward()
+    assert relerr(y.detach(), g['logits']) < RTOL
+    assert relerr(x.grad.norm(), g['dx_norm']) < 1e-4
+    flat = x.grad.reshape(-1)
+    assert relerr(flat[torch.from_numpy(recipe.grad_subsample_index(flat.numel(), 16384))], g['dxsub64']) < 2e-4
+    for k, v in p.items():
+        # (the reference's own float32 and float64 norms differ by up to 2e-4 on this fixture)
+        assert relerr(v.grad.norm(), g['gnorm.' + k]) < 3e-4 and relerr(v.grad.norm(), g['gnorm64.' + k]) < 3e-4, k
+        assert relerr(subsample(v.grad), g['gsub64.' + k]) < 1e-3, k
+
+
+def test_g5c_native_conditioned(golden_dir):
+    g = load(golden_dir, 'G5c_native_conditioned')
+    shapes = {'xcep.model.' + k: v for k, v in R.stem_param_shapes().items()}
+    shapes.update({'vit.' + k: v for k, v in R.dsttr_param_shapes(6, 19).items()})
+    p = R.with_grad(cond_params(shapes, ''))
+    x = torch.from_numpy(recipe.correlated_frames('g5c.x', (1, 6, 3, 300, 300)))
+    logits = R.xception_vidtr_forward(p, x)
+    loss = R.bce_with_logits(logits, torch.ones(1))
+    loss.backward()
+    assert relerr(logits.detach(), g['logits']) < 2e-5
+    assert relerr(loss.detach(), g['loss']) < 1e-5
+    live = [str(s) for s in g['live_param_names']]
+    assert sorted(live) == sorted(k for k, v in p.items() if v.requires_grad)
+    for k in live:
+        assert relerr(p[k].grad.norm(), g['gnorm.' + k]) < 3e-4, k
+        assert cosine(subsample(p[k].grad), g['gsub64.' + k]) > 0.999999, k
