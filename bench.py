@@ -866,6 +866,14 @@ def headline(a, world, rank, local_rank, multi):
 
 def main():
     a = parse()
+    wd = float(os.environ.get('ISTVT_BENCH_WATCHDOG', '900'))
+    if wd > 0:
+        # a run that is still alive after this many seconds dumps every thread's Python stack to stderr (and goes on):
+        # a hang in a rendezvous / collective / launcher then says where it is (the default run takes about a minute;
+        # ISTVT_BENCH_WATCHDOG=0 switches it off).  It found the one hang this path has had: a tcp:// rendezvous of the
+        # one-rank RCCL rehearsal under torchrun, which makes every rank a CLIENT of the agent's store.
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, repeat=True, file=sys.stderr)
     if (a.gpus > 1 or a.self_launch) and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(a))
     _import_torch()
@@ -896,8 +904,14 @@ def main():
                 port = s.getsockname()[1]
             os.environ['ISTVT_FORCE_COLLECTIVES'] = '1'
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
-                                    device_id=torch.device('cuda', 0))
+            if 'WORLD_SIZE' in os.environ and 'MASTER_PORT' in os.environ:
+                # started by torch.distributed.run (--self-launch --gpus 1): the launcher's own rendezvous -- under the
+                # elastic agent (TORCHELASTIC_USE_AGENT_STORE) a tcp:// init would make even rank 0 a client of a store
+                # that nobody serves
+                dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+            else:
+                dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                        device_id=torch.device('cuda', 0))
     # `multi`: the collectives of the data-parallel step run (N > 1, or the one-rank RCCL rehearsal)
     multi = world > 1 or a.rccl_rehearsal
     pinned = pin_rank(local_rank, world)
