@@ -183,7 +183,7 @@ def test_wrong_geometry_raises():
         M.FeedForward(DIM, 2 * DIM)(torch.zeros(1, 4, DIM))
 
 
-WQK_CORRELATED_TOL = 0.5          # set from the measurement
+WQK_CORRELATED_TOL = 0.45         # measured 0.384 (the round-3 data flow: 0.481); DESIGN.md section 4
 
 
 def test_temporal_bf16_correlated_frames_tracks_float32():
@@ -242,8 +242,12 @@ def test_temporal_bf16_correlated_frames_tracks_float32():
           'new %.3e old %.3e' % (new_y, old_y, new_dx, old_dx, new_wqk, old_wqk, new_wv, old_wv))
     # the to_qk weight gradient is formed as dq^T y from the ADJOINTED dq and the un-differenced y (exactly
     # dq'^T diff, but every product dq_f y_f is rounded at |y|, not |diff|): measured here, bounded below
+    # Measured: dW(to_v) 5.1e-3 (old 6.9e-3); dW(to_qk) 0.384 (old 0.481) beside dx 0.217 (0.345): the to_qk gradient sits on
+    # the same dS = p (dp - delta) floor as dx (dq' itself is that inaccurate at a 5 % frame change); the |y| / |diff|
+    # amplification of forming it as dq^T y is 2^-9 x 14 ~ 3 % per operand here, an order below that floor.  At the 30 %
+    # frame change of the reference capture G5c every to_qk gradient is within 1.2 % in norm and 0.9998 in direction.
     assert new_wv < 2e-2, new_wv
-    assert new_wqk < WQK_CORRELATED_TOL, new_wqk
+    assert new_wqk < WQK_CORRELATED_TOL and new_wqk < old_wqk, (new_wqk, old_wqk)
     # Measured on MI355X: y 5.2e-3 (round-3 path 7.1e-3), dx 0.22 (0.35).  The output moves little either way -- with
     # correlated frames the rows of V are nearly equal, so P V hardly depends on P -- but the input gradient does: it goes
     # through dS = p (dp - delta), where the same correlation makes dp - delta a difference of nearly equal numbers built
