@@ -43,6 +43,7 @@ struct GemmArgs {
                           // gemm256q<.., STATS = 2>: st_sum only (a bias gradient; folded by istvt_stats_reduce_add)
     int a_sel_col;        // gemm256q: > 0: column tiles at or past this column take their A rows from a SECOND plane,
     int a2_off;           //   a2_off bytes behind A (istvt_gemm flags bit 1: the plane follows the first one, M rows of lda)
+    void* dbg;            // diagnostic builds (-DISTVT_GEMM_DIAG): where the in-kernel stamps go when C2 is a real operand
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -408,6 +409,25 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
             };
 #ifdef ISTVT_GEMM_DIAG
             static const int qdbg = istvt_tune("ISTVT_GEMM_QDBG", 0);
+            if (qdbg && (epi == EPI_GELU_FWD || epi == EPI_GELU_BWD)) {
+                // the GELU epilogues' stamps (round 5): 1024 = per-tile spans only, 1152 = + output stores out of range,
+                // 3072 = + no GELU arithmetic (bit 2048), 3200 = neither; stamps go to the buffer named by ISTVT_GEMM_DBGPTR
+                const char* dp = getenv("ISTVT_GEMM_DBGPTR");
+                a.dbg = dp ? (void*)strtoull(dp, nullptr, 0) : nullptr;
+                if (!a.dbg) return ISTVT_ERR_SHAPE;
+                const int G = pick_grid(tiles, 256);
+                const bool kh = K > 64 && (K & 63) != 0 && (K & 63) <= 32;
+                if (!kh) return ISTVT_ERR_SHAPE;
+#define QG(n) case n: if (epi == EPI_GELU_FWD) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_FWD, false, n, 256, 0, true>), dim3(G), block, 0, stream, a); \
+                      else if (col_sum) hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, n, 256, 2, true>), dim3(G), block, 0, stream, a); \
+                      else hipLaunchKernelGGL((gemm256q_kernel<EPI_GELU_BWD, false, n, 256, 0, true>), dim3(G), block, 0, stream, a); break;
+                switch (qdbg) {
+                    QG(1024) QG(1152) QG(3072) QG(3200)
+                    default: return ISTVT_ERR_SHAPE;
+                }
+#undef QG
+                return istvt_check_launch();
+            }
             if (qdbg && epi == 0 && !residual) {
                 const int G = pick_grid(tiles, 256);
 #define QD(n) case n: hipLaunchKernelGGL((gemm256q_kernel<0, false, n>), dim3(G), block, 0, stream, a); break;

@@ -145,6 +145,11 @@ __device__ __forceinline__ void slot_barrier() {
 #ifndef ISTVT_Q_STORE_AUX
 #define ISTVT_Q_STORE_AUX (STATS == 1 ? 0 : 2)
 #endif
+// the GELU-forward epilogue's SECOND output, gelu(u): the A operand of the very next GEMM (module.py:28-30), while u is
+// read a whole layer later (the backward pass)
+#ifndef ISTVT_Q_STORE_AUX2
+#define ISTVT_Q_STORE_AUX2 ISTVT_Q_STORE_AUX
+#endif
 template <int EPI, bool SIDE, int DBG = 0, int TM = 256, int STATS = 0, bool KHALF = false>
 __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     static_assert(TM == 256 || TM == 224, "row tile");
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                     const bf16x8 u = __builtin_bit_cast(bf16x8, sv[pass * 2 + it]);
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
+                        if constexpr ((DBG & 2048) != 0) { v[j] *= (float)u[j]; v[j + 1] *= (float)u[j + 1]; continue; }   // no GELU arithmetic
                         const gf2 gg = gelu_grad_fast2(gf2{(float)u[j], (float)u[j + 1]});
                         v[j] *= gg.x; v[j + 1] *= gg.y;
                     }
@@ -852,11 +858,12 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                     bf16x8 o2;
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
+                        if constexpr ((DBG & 2048) != 0) { o2[j] = (bf16_t)(v[j] + 1.0f); o2[j + 1] = (bf16_t)(v[j + 1] + 1.0f); continue; }
                         const gf2 gv = gelu_fast2(gf2{v[j], v[j + 1]});
                         o2[j] = (bf16_t)gv.x; o2[j + 1] = (bf16_t)gv.y;
                     }
                     held2[it] = __builtin_bit_cast(u32x4, o2);
-                    __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, ISTVT_Q_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(held2[it], c2_rs, voff, soff, ISTVT_Q_STORE_AUX2);
                 }
             }
             // STORE-DATA HAZARD, see gemm_shared.h
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
     if constexpr (SCHED == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the out-of-range pieces past the stream's end
     if constexpr ((DBG & 1280) != 0) {
         if (lane == 0) {
-            unsigned long long* d = (unsigned long long*)p.C2 + ((long)blockIdx.x * 8 + wave) * 24;
+            unsigned long long* d = (unsigned long long*)(p.dbg ? p.dbg : p.C2) + ((long)blockIdx.x * 8 + wave) * 24;
 #pragma unroll
             for (int j = 0; j < 12; ++j) d[j] = seg[j];
             d[12] = clk_c; d[13] = clk_r; d[14] = (unsigned long long)my_tiles * nkt; d[15] = 1;
