@@ -173,15 +173,24 @@ __device__ __forceinline__ float group_sum(float v) { return xgroup_sum(v); }
 // the query blocks itself, instead of ceil(P / 128) workgroups that each stage all keys (P = 197: two workgroups, K and
 // V fetched twice, 1.57x the algorithmic bytes by the PMC pass; the kernel is bound by that traffic).  After the one
 // barrier behind the staging the wavefronts run independently: no chunk barriers, no re-staging.
-constexpr int RES_CHUNKS = 2;
+// Round 5: RES is the number of resident 128-row chunks, 2 (P <= 256: 224^2 inputs, P = 197) or 3 (P <= 384: the reference's
+// own 300^2 geometry, P = 362 -- two images of 384 rows = 120 KiB, one workgroup per CU).  Three chunks are BUILT and tested
+// (-DISTVT_SATTN_RES_MAX=3) but not dispatched: measured at the reference's geometry (112 frames x 8 heads, P = 362, same
+// box, alternating; profiles/r05_b_*): forward 90.4 us resident against 81.2 us on the chunked kernels (three workgroups per
+// problem, K / V fetched three times but 4 workgroups per CU instead of 1), backward 236 against 233 us; P = 300: 68 vs 61,
+// 180 vs 189.  The chunked kernels already run P = 362 at the TFLOP/s of P = 197 (330-380 forward, 320 backward).
+#ifndef ISTVT_SATTN_RES_MAX
+#define ISTVT_SATTN_RES_MAX 2
+#endif
+constexpr int RES_CHUNKS_MAX = ISTVT_SATTN_RES_MAX;
 // RES kernels: the two LDS images hold img_rows = P rounded up to 32 rows (zero-filled past P), in dynamic shared memory
 // sized by the host -- P = 197: 2 x 224 rows x 160 bytes = 70 KiB, two workgroups per CU (256-row images at this pitch
 // would be 80 KiB + statistics: one).
 extern __shared__ __attribute__((aligned(16))) char sattn_dyn[];
 __host__ __device__ inline int res_img_rows(int P) { return (P + 31) & ~31; }
 
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
-__global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+template <typename T, int DH, int U, bool FP8 = false, int RES = 0>
+__global__ __launch_bounds__(512 / U, (U == 1 && RES < 3) ? 4 : 1) void sattn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         float* __restrict__ lse, int P, int heads, float scale, long ldqkv, long ldo) {
     constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
     const T* vp = base + 2 * inner + h * DH;
 #endif
     const float c = scale * LOG2E;
-    constexpr int NBLK = RES ? RES_CHUNKS : 1;
+    constexpr int NBLK = RES ? RES : 1;
     // the query rows of EVERY block this wavefront will own are requested first: in RES mode their latency then hides
     // behind the staging (a global-memory round trip under load is ~2 us: one per block was a third of a wavefront's life)
     typename Mma<T>::frag qf_pre[NBLK][U][KS];
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(512 / U, U == 1 ? 4 : 1) void sattn_fwd_kernel(cons
                 qf_pre[qi][u][ks] = row_frag<T>(qp, ld, (RES ? qi : (int)blockIdx.x) * 128 + wave * 16 * U + 16 * u + r, P,
                                                 32 * ks + 8 * g);
     if constexpr (RES) {
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid, img_rows);
+        stage_all2<T, DH, 512 / U, RES>(Kimg, kp, ld, Vimg, vp, ld, P, tid, img_rows);
         __syncthreads();
     }
 #pragma unroll
@@ -403,12 +412,12 @@ template <typename T, int DH, int U, int NBLK> struct SattnKeep {
 };
 
 // FUSED (sattn_bwd_fused_kernel): delta goes to the LDS row the dK / dV part reads it from instead of to global memory
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false, bool FUSED = false>
+template <typename T, int DH, int U, bool FP8 = false, int RES = 0, bool FUSED = false>
 __device__ __forceinline__ void sattn_dq_body(const T* __restrict__ qkv, const T* __restrict__ out,
                                               const T* __restrict__ dout, const float* __restrict__ lse,
                                               float* __restrict__ delta, T* __restrict__ dqkv, int P,
                                               int heads, float scale, long ldqkv, long ldo,
-                                              SattnKeep<T, DH, U, RES ? RES_CHUNKS : 1>* keep = nullptr) {
+                                              SattnKeep<T, DH, U, RES ? RES : 1>* keep = nullptr) {
     static_assert(!FUSED || RES, "the fused backward is the keys-resident form");
     constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
@@ -426,7 +435,7 @@ __device__ __forceinline__ void sattn_dq_body(const T* __restrict__ qkv, const T
     const T* op = out + (long)bf * P * ldo + h * DH;
     const T* dop = dout + (long)bf * P * ldo + h * DH;
     const float c = scale * LOG2E;
-    constexpr int NBLK = RES ? RES_CHUNKS : 1;
+    constexpr int NBLK = RES ? RES : 1;
     // rows of every query block this wavefront will own, requested before the staging (see sattn_fwd_kernel)
     typename Mma<T>::frag qf_pre[NBLK][U][KS], dof_pre[NBLK][U][KS], of_pre[NBLK][U][KS];
     float2 st_pre[NBLK][U];
@@ -445,7 +454,7 @@ __device__ __forceinline__ void sattn_dq_body(const T* __restrict__ qkv, const T
             st_pre[qi][u] = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
         }
     if constexpr (RES) {                               // every key / value row staged once (see sattn_fwd_kernel)
-        stage_all2<T, DH, 512 / U, RES_CHUNKS>(Kimg, kp, ld, Vimg, vp, ld, P, tid, img_rows);
+        stage_all2<T, DH, 512 / U, RES>(Kimg, kp, ld, Vimg, vp, ld, P, tid, img_rows);
         __syncthreads();
     }
 #pragma unroll
@@ -572,7 +581,7 @@ __device__ __forceinline__ void sattn_dq_body(const T* __restrict__ qkv, const T
   }   // query blocks
 }
 
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
+template <typename T, int DH, int U, bool FP8 = false, int RES = 0>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                            const T* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ delta, T* __restrict__ dqkv, int P,
@@ -582,12 +591,12 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dq_kernel(const T* __restri
 
 // ------------------------------------------------------------------------------------------
 // backward part 2: dK, dV.  Wave owns 32 keys; queries stream through LDS.
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false, bool FUSED = false>
+template <typename T, int DH, int U, bool FP8 = false, int RES = 0, bool FUSED = false>
 __device__ __forceinline__ void sattn_dkv_body(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                const float* __restrict__ lse,
                                                const float* __restrict__ delta, T* __restrict__ dqkv,
                                                int P, int heads, float scale, long ldqkv, long ldo,
-                                               const SattnKeep<T, DH, U, RES ? RES_CHUNKS : 1>* keep = nullptr) {
+                                               const SattnKeep<T, DH, U, RES ? RES : 1>* keep = nullptr) {
     constexpr int LDI = Pitch<T, DH>::v, KS = DH / 32, DT = DH / 16;
     __shared__ __attribute__((aligned(16))) T smem_st[RES ? 8 : 2 * CHUNK * LDI];
     __shared__ __attribute__((aligned(16))) float stat_st[RES ? 4 : 2 * CHUNK];
@@ -606,7 +615,7 @@ __device__ __forceinline__ void sattn_dkv_body(const T* __restrict__ qkv, const 
     const T* vp = base + 2 * inner + h * DH;
     const T* dop = dout + (long)bf * P * ldo + h * DH;
     const float c = scale * LOG2E;
-    constexpr int NBLK = RES ? RES_CHUNKS : 1;
+    constexpr int NBLK = RES ? RES : 1;
     // key / value rows of every block this wavefront will own, requested before the staging (see sattn_fwd_kernel)
     typename Mma<T>::frag kf_pre[NBLK][U][KS], vf_pre[NBLK][U][KS];
 #pragma unroll
@@ -651,7 +660,7 @@ __device__ __forceinline__ void sattn_dkv_body(const T* __restrict__ qkv, const 
                     }
                 }
         } else {
-            stage_all2<T, DH, 512 / U, RES_CHUNKS>(Qimg, qp, ld, Dimg, dop, ldo, P, tid, img_rows);
+            stage_all2<T, DH, 512 / U, RES>(Qimg, qp, ld, Dimg, dop, ldo, P, tid, img_rows);
         }
         for (int q = tid; q < img_rows; q += 512 / U) {
             const float2 st = q < P ? reinterpret_cast<const float2*>(lse)[((long)bf * P + q) * heads + h] : make_float2(0.f, 0.f);
@@ -781,7 +790,7 @@ __device__ __forceinline__ void sattn_dkv_body(const T* __restrict__ qkv, const 
   }   // key blocks
 }
 
-template <typename T, int DH, int U, bool FP8 = false, bool RES = false>
+template <typename T, int DH, int U, bool FP8 = false, int RES = 0>
 __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                             const float* __restrict__ lse,
                                                             const float* __restrict__ delta, T* __restrict__ dqkv,
@@ -794,15 +803,15 @@ __global__ __launch_bounds__(512 / U) void sattn_bwd_dkv_kernel(const T* __restr
 // stay on the CU -- the wavefronts' own key rows are read from the K / V images before they are overwritten, the Q / dO
 // images are written from the row fragments the dQ part loaded -- and delta passes through LDS: every operand is read from
 // global memory once (HBM-side traffic 1.69 x -> 1.0 x of the algorithmic bytes), one launch instead of two.
-template <typename T, int DH, bool FP8 = false>
+template <typename T, int DH, bool FP8 = false, int NCH = 2>
 __global__ __launch_bounds__(512) void sattn_bwd_fused_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                               const T* __restrict__ dout, const float* __restrict__ lse,
                                                               T* __restrict__ dqkv, int P, int heads, float scale,
                                                               long ldqkv, long ldo) {
-    SattnKeep<T, DH, 1, RES_CHUNKS> keep;
-    sattn_dq_body<T, DH, 1, FP8, true, true>(qkv, out, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
+    SattnKeep<T, DH, 1, NCH> keep;
+    sattn_dq_body<T, DH, 1, FP8, NCH, true>(qkv, out, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
     __syncthreads();                    // every wavefront is done with the K / V images
-    sattn_dkv_body<T, DH, 1, FP8, true, true>(qkv, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
+    sattn_dkv_body<T, DH, 1, FP8, NCH, true>(qkv, dout, lse, nullptr, dqkv, P, heads, scale, ldqkv, ldo, &keep);
 }
 
 #include "attn_spatial_pers.h"
@@ -826,6 +835,12 @@ static int res_lds(K kernel, int P, int dh, bool with_stats, size_t* bytes) {
         return ISTVT_ERR_LAUNCH;
     return ISTVT_OK;
 }
+// RC = resident chunks for this P (2 or 3) as a constant expression
+#define DISPATCH_RC(PV, ...)                                     \
+    do {                                                         \
+        if ((PV) <= 2 * CHUNK) { constexpr int RC = 2; __VA_ARGS__; } \
+        else { constexpr int RC = 3; __VA_ARGS__; }              \
+    } while (0)
 #define LAUNCH_RES(KERNEL, STATS, ...)                                                            \
     do {                                                                                          \
         size_t lds_ = 0;                                                                          \
@@ -867,9 +882,9 @@ extern "C" int istvt_attn_spatial_fwd(const void* qkv, long ldqkv, void* out, lo
 #undef SP_LAUNCH
             return istvt_check_launch();
         }
-        if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {      // one workgroup per (frame, head), keys resident (P = 197 at 224^2)
-            DISPATCH_DH(dh, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, false, true>), false, (const bf16_t*)qkv, (bf16_t*)out, lse,
-                                       P, heads, scale, ldqkv, ldo));
+        if (P > CHUNK && P <= RES_CHUNKS_MAX * CHUNK) {      // one workgroup per (frame, head), keys resident (P = 197 at 224^2)
+            DISPATCH_DH(dh, DISPATCH_RC(P, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, false, RC>), false, (const bf16_t*)qkv, (bf16_t*)out, lse,
+                                       P, heads, scale, ldqkv, ldo)));
             return istvt_check_launch();
         }
         DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1>), grid, dim3(512), 0, stream,
@@ -890,18 +905,18 @@ extern "C" int istvt_attn_spatial_bwd(const void* qkv, long ldqkv, const void* o
     if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     dim3 grid((P + 127) / 128, BF * heads);
     static const int fused = istvt_tune("ISTVT_SATTN_FUSED_BWD", 1);
-    if (fused && dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        DISPATCH_DH(dh, LAUNCH_RES((sattn_bwd_fused_kernel<bf16_t, DH>), true, (const bf16_t*)qkv, (const bf16_t*)out,
-                                   (const bf16_t*)dout, lse, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo));
+    if (fused && dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS_MAX * CHUNK) {
+        DISPATCH_DH(dh, DISPATCH_RC(P, LAUNCH_RES((sattn_bwd_fused_kernel<bf16_t, DH, false, RC>), true, (const bf16_t*)qkv, (const bf16_t*)out,
+                                   (const bf16_t*)dout, lse, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo)));
         return istvt_check_launch();
     }
-    if (dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        DISPATCH_DH(dh, {
-            LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, true>), false, (const bf16_t*)qkv, (const bf16_t*)out,
+    if (dtype == DT_BF16 && P > CHUNK && P <= RES_CHUNKS_MAX * CHUNK) {
+        DISPATCH_DH(dh, DISPATCH_RC(P, {
+            LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, false, RC>), false, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
-            LAUNCH_RES((sattn_bwd_dkv_kernel<bf16_t, DH, 1, false, true>), true, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+            LAUNCH_RES((sattn_bwd_dkv_kernel<bf16_t, DH, 1, false, RC>), true, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                        (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
-        });
+        }));
         return istvt_check_launch();
     }
     if (dtype == DT_BF16) {                     // 8 wavefronts x 16 rows, see sattn_fwd_kernel
@@ -932,9 +947,9 @@ extern "C" int istvt_attn_spatial_fwd_fp8(const void* qkv, long ldqkv, void* out
     if (ldqkv < 3L * heads * dh || ldo < (long)heads * dh || ldqkv % 8 || ldo % 8) return ISTVT_ERR_SHAPE;
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
-    if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        DISPATCH_DH(dh, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, true, true>), false, (const bf16_t*)qkv, (bf16_t*)out, lse, P,
-                                   heads, scale, ldqkv, ldo));
+    if (P > CHUNK && P <= RES_CHUNKS_MAX * CHUNK) {
+        DISPATCH_DH(dh, DISPATCH_RC(P, LAUNCH_RES((sattn_fwd_kernel<bf16_t, DH, 1, true, RC>), false, (const bf16_t*)qkv, (bf16_t*)out, lse, P,
+                                   heads, scale, ldqkv, ldo)));
         return istvt_check_launch();
     }
     DISPATCH_DH(dh, hipLaunchKernelGGL((sattn_fwd_kernel<bf16_t, DH, 1, true>), grid, dim3(512), 0, stream,
@@ -950,18 +965,18 @@ extern "C" int istvt_attn_spatial_bwd_fp8(const void* qkv, long ldqkv, const voi
     if (dtype != DT_BF16) return ISTVT_ERR_DTYPE;
     dim3 grid((P + 127) / 128, BF * heads);
     static const int fused = istvt_tune("ISTVT_SATTN_FUSED_BWD", 1);
-    if (fused && P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        DISPATCH_DH(dh, LAUNCH_RES((sattn_bwd_fused_kernel<bf16_t, DH, true>), true, (const bf16_t*)qkv, (const bf16_t*)out,
-                                   (const bf16_t*)dout, lse, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo));
+    if (fused && P > CHUNK && P <= RES_CHUNKS_MAX * CHUNK) {
+        DISPATCH_DH(dh, DISPATCH_RC(P, LAUNCH_RES((sattn_bwd_fused_kernel<bf16_t, DH, true, RC>), true, (const bf16_t*)qkv, (const bf16_t*)out,
+                                   (const bf16_t*)dout, lse, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo)));
         return istvt_check_launch();
     }
-    if (P > CHUNK && P <= RES_CHUNKS * CHUNK) {
-        DISPATCH_DH(dh, {
-            LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, true>), false, (const bf16_t*)qkv, (const bf16_t*)out,
+    if (P > CHUNK && P <= RES_CHUNKS_MAX * CHUNK) {
+        DISPATCH_DH(dh, DISPATCH_RC(P, {
+            LAUNCH_RES((sattn_bwd_dq_kernel<bf16_t, DH, 1, true, RC>), false, (const bf16_t*)qkv, (const bf16_t*)out,
                        (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
-            LAUNCH_RES((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true, true>), true, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+            LAUNCH_RES((sattn_bwd_dkv_kernel<bf16_t, DH, 1, true, RC>), true, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                        (const float*)delta, (bf16_t*)dqkv, P, heads, scale, ldqkv, ldo);
-        });
+        }));
         return istvt_check_launch();
     }
     DISPATCH_DH(dh, {

@@ -401,7 +401,8 @@ def cast_transpose(R=1000, C=728):
 def all_checks():
     """-> list of (name, callable)"""
     out = [('cast_transpose', cast_transpose), ('cast_transpose_tail', lambda: cast_transpose(520, 1544)),
-           ('attn_spatial_fp8_P197', attn_spatial_fp8), ('attn_spatial_fp8_P37', lambda: attn_spatial_fp8(4, 37, 8, 64))]
+           ('attn_spatial_fp8_P197', attn_spatial_fp8), ('attn_spatial_fp8_P37', lambda: attn_spatial_fp8(4, 37, 8, 64)),
+           ('attn_spatial_fp8_P362', lambda: attn_spatial_fp8(2, 362, 8, 64))]
     for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
         for mode in ('fwd', 'dgrad', 'wgrad'):
             out.append(('gemm_exact_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode)))
@@ -423,8 +424,10 @@ def all_checks():
         out.append(('layernorm_bwd_deferred_%s' % tag, lambda dt=dt: layernorm_bwd_deferred(dt)))
         out.append(('frame_diff_%s' % tag, lambda dt=dt: frame_diff(dt)))
         # (129 .. 256 keys: the keys-resident kernels incl. the fused backward -- smallest, 32-multiples, largest)
+        # (257 .. 384 keys, round 5: three resident chunks -- the reference's own P = 362 --: smallest, a 32-multiple, largest;
+        #  385: back on the chunked kernels)
         for P, heads, dh in ((197, 8, 64), (37, 8, 64), (362, 2, 32), (362, 8, 64), (128, 2, 64), (129, 2, 64), (160, 8, 64),
-                             (200, 2, 32), (224, 8, 64), (256, 2, 64)):
+                             (200, 2, 32), (224, 8, 64), (256, 2, 64), (257, 2, 64), (288, 8, 64), (384, 2, 64), (385, 2, 64)):
             out.append(('attn_spatial_P%d_h%d_d%d_%s' % (P, heads, dh, tag),
                         lambda dt=dt, P=P, heads=heads, dh=dh: attn_spatial(dt, 3, P, heads, dh)))
         for F, heads, dh in ((9, 8, 64), (5, 2, 32), (17, 8, 64), (7, 8, 64), (17, 2, 32)):

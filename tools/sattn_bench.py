@@ -15,7 +15,7 @@ if os.environ.get('GB_LIB'):            # A/B a variant build of the library (sa
     _lib.LIB_PATH = os.path.abspath(os.environ['GB_LIB'])
 
 dt = torch.bfloat16
-BF, heads, dh = 288, 8, 64
+BF, heads, dh = int(os.environ.get('SA_BF', 288)), 8, 64
 
 
 def timeit(fn, reps=10):
