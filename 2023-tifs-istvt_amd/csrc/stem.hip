@@ -593,6 +593,36 @@ __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in,
     }
 }
 
+// The tile fill WITHOUT a transform (no BatchNorm pack, no ReLU: every input-gradient launch -- the operand is a plain
+// gradient -- and a stand-alone SeparableConv2d), bfloat16: LDS-DMA.  A wave instruction moves 64 lanes x 16 bytes =
+// eight consecutive LDS pixels (a pixel's 64 channels are 128 bytes = 8 lanes); pixels outside the image, channel chunks
+// past C and the pixels past the tile's end are out of range for the frame's descriptor and arrive as zeros -- the
+// convolution's zero padding.  23 instructions per tile (6 per wavefront) replace the register fill's 6 loads + 6 x
+// (8 conversions up, 8 down, the LDS store and its address arithmetic) per thread.  The caller waits (vmcnt(0)) before
+// its barrier.  The LDS tile needs DW_DMA_PAD elements of slack (the last instruction covers pixels 176 .. 183 of 180).
+constexpr int DW_DMA_INSTR = (DW_LH * DW_LW + 7) / 8;
+constexpr int DW_DMA_PAD = (DW_DMA_INSTR * 8 - DW_LH * DW_LW) * DW_CC;
+__device__ __forceinline__ void dw_load_tile_dma(bf16_t* tile, const bf16_t* __restrict__ in, long f, int y0, int x0, int c0,
+                                                 int H, int W, int C, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned long long u = (unsigned long long)(in + f * H * W * C);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                                                        H * W * C * 2, 0x00020000u);
+    const unsigned lds0 = (unsigned)(__SIZE_TYPE__)(__attribute__((address_space(3))) void*)tile;
+    const int c = c0 + (lane & 7) * 8;
+#pragma unroll
+    for (int k = 0; k < (DW_DMA_INSTR + 3) / 4; ++k) {
+        const int it = wave + 4 * k;
+        if (it >= DW_DMA_INSTR) break;                       // wave-uniform
+        const int i = it * 8 + (lane >> 3);
+        const int py = i / DW_LW, px = i - py * DW_LW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = i < DW_LH * DW_LW && y >= 0 && y < H && x >= 0 && x < W && c < C;
+        dma16_lds(rs, lds0 + it * 1024, ok ? (unsigned)(((y * W + x) * C + c) * 2) : 0x80000000u, 0);
+    }
+}
+
 // dw_load_tile in two halves, for a caller that keeps the NEXT tile's global loads in flight under the current tile's
 // arithmetic (dwconv3x3_wgrad_kernel, round 4): fetch = every global load of the tile into registers, commit = BatchNorm
 // pack / ReLU / conversion and the (swizzled, float) LDS stores.
@@ -659,7 +689,7 @@ __device__ __forceinline__ void dw_strip(int tid, int& strip, int& px) {
 // gradient launches costs ~90 registers; compiled into one kernel it left the forward at two workgroups per CU too.
 template <typename T, bool EPI>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
-    __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS];
+    __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS + DW_DMA_PAD];
     __shared__ float sred[2][4][DW_CC];   // [s1|s2][wave][channel]
     __shared__ __attribute__((aligned(16))) float wsm[9][DW_CC];
     __shared__ __attribute__((aligned(16))) float bnsm[EPI ? 4 : 1][DW_CC];   // the mask source's BatchNorm pack (mean, rstd, scale, beta)
@@ -701,7 +731,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
             }
         }
     }
-    dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
+    bool dma_fill = false;
+    if constexpr (sizeof(T) == 2) {
+#ifndef ISTVT_DW_NO_DMA_FILL
+        dma_fill = !p.in_bn && !p.in_relu && (long)p.H * p.W * p.C * 2 < 0x7fffffffL;        // workgroup-uniform
+#endif
+        if (dma_fill) dw_load_tile_dma((bf16_t*)tile, (const bf16_t*)p.in, f, y0, x0, c0, p.H, p.W, p.C, tid);
+    }
+    if (!dma_fill) dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
 #ifdef ISTVT_DW_DIAG
     tstamp[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -728,6 +765,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
             store8(&bnsm[row][wc], b8);
         }
     }
+    if (dma_fill) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's DMA pieces have landed
     __syncthreads();
 #ifdef ISTVT_DW_DIAG
     tstamp[2] = __builtin_amdgcn_s_memtime();
