@@ -156,10 +156,13 @@ def test_224_fwd_bwd_vs_oracle(T):
     named = dict(model.named_parameters())
     errs = sorted(((relerr(named[k].grad.norm(), v.grad.norm()), k) for k, v in pr.items()
                    if v.requires_grad and v.grad is not None), reverse=True)
+    # gradient norms rtol 1e-2 -- held for every transformer tensor; the stem keeps 2e-2 (a ReLU / arg-max
+    # decision at |z| ~ 1e-6 that lands differently under another fp32 summation order moves early-layer gradients by O(1e-2))
     assert errs[0][0] < 2e-2, errs[:5]
+    assert max(e for e, k in errs if k.startswith('vit.')) < 1e-2, [r for r in errs if r[1].startswith('vit.')][:5]
     dirs = sorted(((relerr(named[k].grad, v.grad), k) for k, v in pr.items()
                    if v.requires_grad and v.grad is not None and k.startswith('vit.')), reverse=True)
-    assert dirs[0][0] < 2e-2, dirs[:5]
+    assert dirs[0][0] < 1e-2, dirs[:5]
 
 
 def test_bf16_mode_tracks_fp32():
@@ -485,6 +488,7 @@ def test_depth12_fp32_and_bf16_vs_oracle():
                   reverse=True)
     print('depth-12 fp32 worst gradient-norm errors vs oracle:', errs[:4])
     assert errs[0][0] < 2e-2, errs[:5]
+    assert max(e for e, k in errs if k.startswith('vit.')) < 1e-2, [r for r in errs if r[1].startswith('vit.')][:5]
     del m32, n32
     m16 = _hip_model(p, 8, grid, 12, dtype=torch.bfloat16)
     o16 = m16(x.cuda())
