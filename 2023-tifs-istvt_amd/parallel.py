@@ -220,6 +220,55 @@ class GradBucket:
         self._scale(world)
 
 
+class HostScalar:
+    """The value of a device scalar on the host WITHOUT draining the launch queue.
+
+    ``loss.item()`` (train_CNN.py:534) copies on the current stream: it returns when everything enqueued before it -- the
+    whole backward pass and the optimizer step -- has run, and the next step then starts from an empty queue (measured at
+    C2: +1.4 ... 2.1 ms per step; the copy itself is nothing).  ``HostScalar(loss)`` created where the value is PRODUCED
+    (right after the loss / the accuracy count, before ``backward()``) records an event there and copies device -> pinned
+    host memory on a stream of its own behind that event; ``.item()`` -- called where the loop needs the number, after
+    ``optimizer.step()`` -- waits for that copy only, which finished while the backward pass was still running.  Same
+    values at the same program points as the reference loop, no device-wide sync (tools/host_boundary_probe.py:
+    53.5 ms per step against 54.9 with ``.item()``, 53.1 with resident inputs and no readback)."""
+
+    _streams: dict = {}
+
+    def __init__(self, t: torch.Tensor):
+        if t.numel() != 1:
+            raise ValueError('HostScalar takes a one-element tensor')
+        t = t.detach().reshape(1)
+        if not t.is_cuda:                       # nothing to overlap: a host tensor is its own value
+            self._value, self._done, self._buf = t[0].item(), None, None
+            return
+        idx = t.device.index
+        side = HostScalar._streams.get(idx)
+        if side is None:
+            side = HostScalar._streams[idx] = torch.cuda.Stream(device=t.device)
+        self._buf = torch.empty((1,), dtype=t.dtype).pin_memory()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(t.device))
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            self._buf.copy_(t, non_blocking=True)
+            self._done = torch.cuda.Event()
+            self._done.record(side)
+        t.record_stream(side)                   # the allocator must not hand t's block out before the copy has read it
+        self._value = None
+
+    def item(self):
+        if self._value is None:
+            self._done.synchronize()
+            self._value = self._buf[0].item()
+        return self._value
+
+    def __float__(self):
+        return float(self.item())
+
+    def __int__(self):
+        return int(self.item())
+
+
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):
     """identical weights/buffers on every rank (DataParallel replicates module 0 each step)."""
     if not (dist.is_available() and dist.is_initialized()) or _single_rank(group):

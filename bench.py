@@ -526,7 +526,7 @@ def headline(a, world, rank, local_rank, multi):
     if a.dead_row_elimination:
         model.set_dead_row_elimination(True)
 
-    def step(reduce=True, xin=None, lab=None, want_logits=False):
+    def step(reduce=True, xin=None, lab=None, want_logits=False, after_loss=None):
         xin = x if xin is None else xin
         lab = labels if lab is None else lab
         if a.eval:
@@ -538,6 +538,8 @@ def headline(a, world, rank, local_rank, multi):
             opt.zero_grad()                 # a pass only before the first step: the fused step re-zeroes the gradients
         logits = model(xin)
         loss = crit(logits.view(-1), lab)
+        if after_loss is not None:
+            after_loss(loss, logits)
         loss.backward()
         if reduce:
             bucket.all_reduce()
@@ -680,32 +682,59 @@ def headline(a, world, rank, local_rank, multi):
                 dlab[i % 2].copy_(pin_l[i % 2], non_blocking=True)
                 ready[i % 2].record(copy_stream)
 
-        def hb_steps(n):
+        def hb_steps(n, scoped):
             correct, running = 0, 0.0
             upload(0)
             for i in range(n):
                 torch.cuda.current_stream(dev).wait_event(ready[i % 2])
                 if i + 1 < n:
-                    upload(i + 1)           # its buffer was last read by step i - 1, which the .item() below has waited for
-                loss_i, logits_i = step(xin=dbuf[i % 2], lab=dlab[i % 2], want_logits=True)
-                preds = (logits_i.view(-1) > 0).float()
-                running += loss_i.item()                              # the per-step device -> host sync of the reference
-                correct += int(torch.sum(preds == dlab[i % 2]).item())
+                    # its buffer was last read by step i - 1: complete when the .item() below has returned (plain form);
+                    # in the scoped form the copy stream waits for this step's position in the launch stream instead
+                    if scoped:
+                        copy_stream.wait_stream(torch.cuda.current_stream(dev))
+                    upload(i + 1)
+                if scoped:
+                    # the same numbers at the same program points, each read back behind the event of ITS producer
+                    # (parallel.HostScalar) instead of behind the whole step
+                    hs = {}
+
+                    def grab(loss_t, logits_t, lab_t=dlab[i % 2], hs=hs):
+                        hs['loss'] = parallel.HostScalar(loss_t)
+                        hs['acc'] = parallel.HostScalar(torch.sum((logits_t.detach().view(-1) > 0).float() == lab_t))
+                    step(xin=dbuf[i % 2], lab=dlab[i % 2], after_loss=grab)
+                    running += float(hs['loss'])
+                    correct += int(hs['acc'])
+                else:
+                    loss_i, logits_i = step(xin=dbuf[i % 2], lab=dlab[i % 2], want_logits=True)
+                    preds = (logits_i.view(-1) > 0).float()
+                    running += loss_i.item()                              # the per-step device -> host sync of the reference
+                    correct += int(torch.sum(preds == dlab[i % 2]).item())
             return correct, running
-        hb_steps(2)
-        sync()
-        t1 = time.perf_counter()
-        hb_steps(a.steps)
-        sync()
-        e3 = time.perf_counter() - t1
-        if multi:
-            t = torch.tensor([e3], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e3 = float(t.item())
+
+        def hb_timed(scoped):
+            hb_steps(2, scoped)
+            sync()
+            t1 = time.perf_counter()
+            res = hb_steps(a.steps, scoped)
+            sync()
+            e3 = time.perf_counter() - t1
+            if multi:
+                t = torch.tensor([e3], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e3 = float(t.item())
+            return e3, res
+        e3, res_plain = hb_timed(False)
+        e4, res_scoped = hb_timed(True)
         hostb = {'ms_per_step': round(e3 / a.steps * 1e3, 3), 'clips_per_s': round(world * a.batch * a.steps / e3, 3),
                  'h2d_MB_per_step': round(a.batch * a.frames * 3 * a.size * a.size * 4 / 1e6, 1),
                  'note': 'per step: pinned-memory H2D copy of the next batch on a copy stream (hidden under the current '
-                         'step), loss.item() and the accuracy count (train_CNN.py:506,512,534-536); NOT the headline value'}
+                         'step), loss.item() and the accuracy count (train_CNN.py:506,512,534-536); NOT the headline value',
+                 'scoped_readback': {'ms_per_step': round(e4 / a.steps * 1e3, 3),
+                                     'clips_per_s': round(world * a.batch * a.steps / e4, 3),
+                                     'note': 'the same loop with the loss and the accuracy count read back through '
+                                             'parallel.HostScalar (a D2H copy behind the producer\'s own event instead of '
+                                             '.item() on the launch stream, which drains the whole step): same values at '
+                                             'the same program points (INTEGRATION.md: a two-line change of the loop)'}}
 
     # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
     roof = None

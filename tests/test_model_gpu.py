@@ -884,7 +884,7 @@ def test_bench_gpus_n_self_launch_rehearsal():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['distributed']['ranks'] == 2 and out['distributed']['backend'] == 'gloo'
     assert out['value'] > 0 and out['scaling'] == 'weak'
-    assert out['with_host_boundary']['ms_per_step'] > 0
+    assert out['with_host_boundary']['ms_per_step'] > 0 and out['with_host_boundary']['scoped_readback']['ms_per_step'] > 0
 
 
 @pytest.mark.gpu
@@ -1059,3 +1059,28 @@ def test_g5c_native_conditioned_hip(golden_dir, dtype):
 
 BF16_STEM_COS = 0.96            # VERDICT r4 item 2's 0.97 is where the worst stem tensor sits (0.9701): 0.96 leaves it a margin
 BF16_STEM_NORM = 0.15
+
+
+def test_host_scalar_reads_back_without_draining_the_stream():
+    """parallel.HostScalar (train_CNN.py:534-536's loss.item() / accuracy count without the device-wide sync): the value of
+    the tensor AS IT WAS when the HostScalar was made -- later kernels on the launch stream may overwrite the tensor --,
+    returned while work enqueued after it is still running."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    x = torch.full((1,), 3.25, device='cuda')
+    big = torch.randn(8192, 8192, device='cuda')
+    h = parallel.HostScalar(x)
+    for _ in range(20):                     # ~100 ms of work enqueued behind the readback
+        big = big @ big * 1e-4
+    x.add_(1.0)                             # ... and a later write to the same tensor
+    done_early = not torch.cuda.current_stream().query()
+    assert h.item() == 3.25 and float(h) == 3.25
+    assert done_early                       # (the stream still had work when .item() was about to be called)
+    torch.cuda.synchronize()
+    assert float(x) == 4.25
+    s = parallel.HostScalar(torch.tensor([7], device='cuda'))
+    assert int(s) == 7
+    assert parallel.HostScalar(torch.tensor(2.5)).item() == 2.5            # host tensors pass through
+    with pytest.raises(ValueError):
+        parallel.HostScalar(torch.zeros(2, device='cuda'))
