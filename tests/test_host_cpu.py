@@ -466,3 +466,33 @@ def test_cu_reserve_is_a_launch_argument_not_library_state(pkg):
     assert rc == -3
 
 
+
+
+def test_bench_n1_record_round_trip(tmp_path, monkeypatch):
+    """the N = 1 headline record a default run leaves for a later N > 1 run on the same host (bench.n1_cache_write / _read):
+    newest record of THIS host wins, unreadable or foreign files are ignored"""
+    import importlib
+    bench = importlib.import_module('bench')
+    a, b = str(tmp_path / 'a' / 'n1.json'), str(tmp_path / 'b.json')
+    monkeypatch.setattr(bench, 'N1_CACHE', [a, b])
+    assert bench.n1_cache_read() is None
+    out = {'value': 609.0, 'unit': 'clips/s', 'ms_per_step': 52.5, 'config': {'workload': 'C2: ...'},
+           'cpu_baseline': {'value': 0.67, 'cores': 32, 'kind': 'port'}}
+    bench.n1_cache_write(out)
+    rec = bench.n1_cache_read()
+    assert rec['value'] == 609.0 and rec['cpu_baseline']['value'] == 0.67 and rec['age_s'] >= 0 and rec['host'] == os.uname().nodename
+    import json as _json
+    with open(b, 'w') as fh:                                # a record of another host: ignored
+        _json.dump(dict(rec, host='elsewhere', written_unix=rec['written_unix'] + 100, value=1.0), fh)
+    assert bench.n1_cache_read()['value'] == 609.0
+    with open(a, 'w') as fh:
+        fh.write('not json')
+    assert bench.n1_cache_read() is None                    # a: unreadable, b: foreign
+
+
+def test_host_scalar_passes_host_tensors_through(pkg):
+    from istvt_amd import parallel
+    h = parallel.HostScalar(torch.tensor([1.5]))
+    assert h.item() == 1.5 and float(h) == 1.5 and int(parallel.HostScalar(torch.tensor(3))) == 3
+    with pytest.raises(ValueError):
+        parallel.HostScalar(torch.zeros(3))
