@@ -534,6 +534,23 @@ struct DwArgs {
 // A float pixel is 256 bytes = all 64 banks, and a 16-byte access of 16 lanes covers TWO adjacent pixels x 8 chunks x
 // one half: without the swap both pixels hit the same 32 banks (a 2-way conflict on every store and every tap read:
 // SQ_LDS_BANK_CONFLICT was 48 % of the LDS cycles of the weight-gradient kernel), with it they split the banks.
+// ReLU as ONE instruction: fmaxf(v, 0) on a value the compiler cannot prove canonical (a bf16 widened by a shift) is
+// v_max v, v, v + v_max 0, v -- sixteen instead of eight per 8-channel chunk in the issue-bound tile fills.
+// (inline assembly: the compiler folds fmed3(v, 0, inf) and every other spelling back into the canonicalising pair)
+__device__ __forceinline__ float relu1(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// descriptor over ONE frame of an NHWC bf16 tensor: 32-bit offsets, lanes outside the image / past C ask for offset 2^31
+// (out of range: zeros, no branch, no 64-bit address arithmetic)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_frame_rsrc(const bf16_t* in, long f, int H, int W, int C) {
+    const unsigned long long u = (unsigned long long)(in + f * H * W * C);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, H * W * C * 2, 0x00020000u);
+}
+
 template <typename T, typename TT = T, bool SWZ = false>
 __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in, long f, int y0, int x0, int c0, int H,
                                              int W, int C, const float* bnp, int relu, int tid) {
@@ -547,13 +564,27 @@ __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in,
     const int ch = tid % DW_NCH, c = c0 + ch * 8;          // 256 % DW_NCH == 0: same chunk every iteration
     typename Mma<T>::frag raw[NIT];
     bool ok[NIT];
+    if constexpr (sizeof(T) == 2) {
+        // bf16: buffer loads through a per-frame descriptor (frames are far below 2 GiB; the host checks the tile count)
+        const __amdgpu_buffer_rsrc_t rs = dw_frame_rsrc((const bf16_t*)in, f, H, W, C);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + 256 * it;
-        const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        ok[it] = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
-        if (ok[it]) raw[it] = frag_load(in + ((f * H + y) * W + x) * C + c);
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            ok[it] = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
+            const unsigned voff = ok[it] ? (unsigned)(((y * W + x) * C + c) * 2) : 0x80000000u;
+            raw[it] = __builtin_bit_cast(typename Mma<T>::frag, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            ok[it] = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
+            if (ok[it]) raw[it] = frag_load(in + ((f * H + y) * W + x) * C + c);
+        }
     }
     float mu[8], sc[8], be[8];
     if (bnp && c < C) { load8(bnp + c, mu); load8(bnp + 2 * C + c, sc); load8(bnp + 3 * C + c, be); }
@@ -578,7 +609,7 @@ __device__ __forceinline__ void dw_load_tile(TT* tile, const T* __restrict__ in,
             }
             if (relu) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                for (int j = 0; j < 8; ++j) v[j] = relu1(v[j]);
             }
         }
         if constexpr (SWZ) {
@@ -634,13 +665,27 @@ __device__ __forceinline__ void dw_tile_fetch(DwTileRegs<T>& rg, const T* __rest
     constexpr int NVEC = DW_LH * DW_LW * DW_NCH;
     const int ch = tid % DW_NCH, c = c0 + ch * 8;
     rg.ok = 0u;
+    if constexpr (sizeof(T) == 2) {
+        const __amdgpu_buffer_rsrc_t rs = dw_frame_rsrc((const bf16_t*)in, f, H, W, C);      // (see dw_load_tile)
 #pragma unroll
-    for (int it = 0; it < DW_NIT; ++it) {
-        const int i = tid + 256 * it;
-        const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        const bool ok = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
-        if (ok) { rg.raw[it] = frag_load(in + ((f * H + y) * W + x) * C + c); rg.ok |= 1u << it; }
+        for (int it = 0; it < DW_NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const bool ok = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
+            rg.raw[it] = __builtin_bit_cast(typename Mma<T>::frag,
+                                            __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(((y * W + x) * C + c) * 2) : 0x80000000u, 0, 0));
+            rg.ok |= (ok ? 1u : 0u) << it;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < DW_NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int px = (i / DW_NCH) % DW_LW, py = i / (DW_NCH * DW_LW);
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const bool ok = i < NVEC && y >= 0 && y < H && x >= 0 && x < W && c < C;
+            if (ok) { rg.raw[it] = frag_load(in + ((f * H + y) * W + x) * C + c); rg.ok |= 1u << it; }
+        }
     }
 }
 template <typename T>
@@ -664,7 +709,7 @@ __device__ __forceinline__ void dw_tile_commit(float* tile, const DwTileRegs<T>&
             }
             if (relu) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                for (int j = 0; j < 8; ++j) v[j] = relu1(v[j]);
             }
         }
         float* dst = tile + (py * DW_LW + px) * DW_CC + ch * 8;
@@ -687,8 +732,11 @@ __device__ __forceinline__ void dw_strip(int tid, int& strip, int& px) {
 
 // EPI = false: plain convolution (the forward launches).  The mask / skip-add / statistics epilogue of the input-
 // gradient launches costs ~90 registers; compiled into one kernel it left the forward at two workgroups per CU too.
-template <typename T, bool EPI>
+// DMA: the tile is filled by LDS-DMA (bf16 operands that need no transform: the host decides); a template parameter, so that
+// neither instantiation carries the other's fill.
+template <typename T, bool EPI, bool DMA = false>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
+    static_assert(!DMA || sizeof(T) == 2, "the DMA fill moves bf16");
     __shared__ __attribute__((aligned(16))) T tile[DW_TILE_ELEMS + DW_DMA_PAD];
     __shared__ float sred[2][4][DW_CC];   // [s1|s2][wave][channel]
     __shared__ __attribute__((aligned(16))) float wsm[9][DW_CC];
@@ -731,14 +779,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwArgs p) {
             }
         }
     }
-    bool dma_fill = false;
-    if constexpr (sizeof(T) == 2) {
-#ifndef ISTVT_DW_NO_DMA_FILL
-        dma_fill = !p.in_bn && !p.in_relu && (long)p.H * p.W * p.C * 2 < 0x7fffffffL;        // workgroup-uniform
-#endif
-        if (dma_fill) dw_load_tile_dma((bf16_t*)tile, (const bf16_t*)p.in, f, y0, x0, c0, p.H, p.W, p.C, tid);
-    }
-    if (!dma_fill) dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
+    constexpr bool dma_fill = DMA;
+    if constexpr (DMA) dw_load_tile_dma((bf16_t*)tile, (const bf16_t*)p.in, f, y0, x0, c0, p.H, p.W, p.C, tid);
+    else dw_load_tile<T>(tile, (const T*)p.in, f, y0, x0, c0, p.H, p.W, p.C, p.in_bn, p.in_relu, tid);
 #ifdef ISTVT_DW_DIAG
     tstamp[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1108,6 +1151,7 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
                                int mask_pre, int mask_post, const void* addsrc, int Ha, int Wa, double* st_s1,
                                double* st_s2, int dtype, hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0) return ISTVT_ERR_SHAPE;
+    if ((long)H * W * C * 4 >= 0x7fffffffL) return ISTVT_ERR_SHAPE;           // one frame behind a 32-bit buffer descriptor
     if ((mask_pre || mask_post || st_s1) && !msrc) return ISTVT_ERR_SHAPE;
     if (st_s1 && !m_bn) return ISTVT_ERR_SHAPE;
     if (addsrc && !(Ha == H && Wa == W) && (Ha != (H - 1) / 2 + 1 || Wa != (W - 1) / 2 + 1)) return ISTVT_ERR_SHAPE;
@@ -1124,7 +1168,15 @@ extern "C" int istvt_dwconv3x3(const void* in, const float* w, void* out, int Fr
     const long nblk = tiles * ((C + DW_CC - 1) / DW_CC);
     if (nblk > 0x7fffffffL) return ISTVT_ERR_SHAPE;
     dim3 grid((unsigned)nblk);
-    if (msrc || addsrc || st_s1) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), grid, dim3(256), 0, stream, a));
+    const bool epi = msrc || addsrc || st_s1;
+#ifndef ISTVT_DW_NO_DMA_FILL
+    if (dtype == DT_BF16 && !in_bn && !in_relu) {        // no transform on load: the tile arrives by LDS-DMA
+        if (epi) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t, false, true>), grid, dim3(256), 0, stream, a);
+        return istvt_check_launch();
+    }
+#endif
+    if (epi) DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), grid, dim3(256), 0, stream, a));
     else DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), grid, dim3(256), 0, stream, a));
     return istvt_check_launch();
 }
@@ -1147,6 +1199,7 @@ extern "C" int istvt_dwconv3x3_wgrad_ws_elems(int Fr, int H, int W, int C) {
 extern "C" int istvt_dwconv3x3_wgrad(const void* in, const float* in_bn, int in_relu, const void* dout, float* dw,
                                      float* ws, long ws_elems, int Fr, int H, int W, int C, int dtype, hipStream_t stream) {
     if (Fr <= 0 || H <= 0 || W <= 0 || C % 8 != 0 || !ws) return ISTVT_ERR_SHAPE;
+    if ((long)H * W * C * 4 >= 0x7fffffffL) return ISTVT_ERR_SHAPE;           // one frame behind a 32-bit buffer descriptor
     const int cy = (C + DW_CC - 1) / DW_CC;
     const long bx = dww_slots(Fr, H, W, C);
     if (ws_elems < bx * C * 9) return ISTVT_ERR_SHAPE;
