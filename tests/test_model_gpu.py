@@ -909,14 +909,16 @@ def test_bench_real_self_launch_parent_on_this_box():
     out = json.loads(lines[0])
     la = out['launcher']
     assert la['self_launched'] is True and la['parent_imported_torch'] is False and la['parent_mapped_hip_runtime'] is False
-    assert isinstance(la['visible_gpus'], int) and la['visible_gpus'] >= 1, la
+    # (None = neither a *_VISIBLE_DEVICES list nor the KFD sysfs tree is readable on this box: the parent then lets the ranks find out)
+    assert la['visible_gpus'] is None or (isinstance(la['visible_gpus'], int) and la['visible_gpus'] >= 1), la
     assert out['distributed']['backend'] == 'nccl' and out['distributed']['ranks'] == 1 and out['value'] > 0
     assert out['distributed']['without_collectives']['ms_per_step'] > 0
     # more GPUs than the box has: the parent says so (and what it counted from) and starts nothing
     n = la['visible_gpus']
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1), '--steps', '1'],
-                       capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
-    assert r.returncode != 0 and 'GPU(s) visible' in (r.stdout + r.stderr)
+    if n is not None:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1), '--steps', '1'],
+                           capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+        assert r.returncode != 0 and 'GPU(s) visible' in (r.stdout + r.stderr)
 
 
 @pytest.mark.gpu
