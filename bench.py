@@ -325,7 +325,17 @@ def cpu_baseline(frames, size, depth, clips=2, reps=3):
         dn = min(tn)
         nat = {'value': round(1.0 / dn, 4), 'unit': 'clips/s', 's_per_clip': round(dn, 2),
                'sample': 'native: 1 clip, T=6, 300x300, depth 12, fwd+bwd fp32; 1 warm-up + 2 repetitions, best'}
+    host = None
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    host = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {'value': round(clips / dt, 5), 'unit': 'clips/s', 'cores': cores, 'kind': 'port', 'c1_forward': c1, 'native': nat,
+            'host': {'cpu': host, 'hardware_threads': os.cpu_count(), 'torch_threads': torch.get_num_threads()},
             'sample': 'batch of %d clips (T=%d, %dx%d, depth %d) fwd+bwd fp32, oracle/istvt_ref.py, torch %d threads: 1 warm-up + '
                       '%d repetitions, median %.1f s (all: %s)' % (clips, frames, size, size, depth, torch.get_num_threads(), reps,
                                                                  dt, ', '.join('%.1f' % t for t in times))}
