@@ -52,8 +52,8 @@ GF_PER_CLIP_NATIVE = 1483.5                       # the referenc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=8)
     ap.add_argument('--size', type=int, default=224)
