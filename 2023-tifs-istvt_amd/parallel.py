@@ -328,6 +328,11 @@ class _FusedOptimizer(torch.optim.Optimizer):
         self.steps += 1
         self.bucket.grad_scale = 1.0
         ops.invalidate_weight_cache()       # the kernel wrote parameters without bumping their version counters
+        # Re-cast the bf16 operand copies NOW, right behind the update: the bookkeeping (~0.7 ms of Python for ~40 operands)
+        # and the grouped cast launch then happen while the GPU is still working through the backward pass, instead of at
+        # the head of the next forward pass -- where, in a loop that syncs every step (loss.item(), train_CNN.py:534), the
+        # GPU sat idle for it (tools/sync_gap_probe.py: 0.65 ms per step).  The forward's own call finds nothing stale.
+        ops.refresh_stale_operands()
 
     def _slices(self):
         off = 0

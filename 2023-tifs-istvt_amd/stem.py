@@ -492,16 +492,28 @@ class StemFn(Function):
 
 def stem_forward(x: Tensor, xcep: torch.nn.Module, dtype: torch.dtype) -> Tensor:
     """Run the HIP stem with the parameters/buffers of an ``Xception`` module (network/xception.py)."""
-    # look the tensors up by dotted name every call (a load_state_dict / .to() may have replaced them), but without
-    # walking all 12 Xception blocks with named_parameters(): two module-tree walks cost ~1 ms of host time per step
-    params = [xcep.get_parameter(n) for n in param_names()]
+    # The tensors are looked up through their owning submodules every call (a load_state_dict / .to() may have replaced
+    # them): the owners are cached on the module and re-validated by identity (get_submodule per distinct owner), the
+    # parameters / buffers then come straight out of the owners' dicts.  get_parameter / get_buffer by dotted name, 55 per
+    # step, were ~0.4 ms of host time at the very head of a step -- where, in a loop that syncs every step, the GPU waits.
+    refs = xcep.__dict__.get('_istvt_stem_refs')
+    if refs is None or any(xcep.get_submodule(path) is not owner for path, owner in refs[0]):
+        owners = {}
+        for n in list(param_names()) + [b + '.x' for b in bn_names()]:
+            path = n.rpartition('.')[0]
+            if path not in owners:
+                owners[path] = xcep.get_submodule(path)
+        refs = (list(owners.items()), [(owners[n.rpartition('.')[0]], n.rpartition('.')[2]) for n in param_names()],
+                [owners[b] for b in bn_names()])
+        xcep.__dict__['_istvt_stem_refs'] = refs
+    params = [owner._parameters[leaf] for owner, leaf in refs[1]]
     buffers = []
-    for n in bn_names():
-        buffers += [xcep.get_buffer(n + '.running_mean'), xcep.get_buffer(n + '.running_var')]
+    for owner in refs[2]:
+        buffers += [owner._buffers['running_mean'], owner._buffers['running_var']]
     if x.is_cuda:
         stats_arena_reset(x.device)          # one fill for every statistics accumulator of this step
         ops.refresh_stale_operands()         # one grouped cast for every bf16 weight operand the optimizer invalidated
     y = StemFn.apply(x, dtype, xcep.training, buffers, *params)
     if xcep.training:
-        torch._foreach_add_([xcep.get_buffer(n + '.num_batches_tracked') for n in bn_names()], 1)     # one launch, not 11
+        torch._foreach_add_([owner._buffers['num_batches_tracked'] for owner in refs[2]], 1)     # one launch, not 11
     return y

@@ -1086,3 +1086,28 @@ def test_host_scalar_reads_back_without_draining_the_stream():
     assert parallel.HostScalar(torch.tensor(2.5)).item() == 2.5            # host tensors pass through
     with pytest.raises(ValueError):
         parallel.HostScalar(torch.zeros(2, device='cuda'))
+
+
+def test_stem_owner_cache_follows_replaced_submodules():
+    """stem.stem_forward caches the modules that own the stem's parameters / buffers and re-validates them by identity every
+    call: a submodule replaced after the first forward (not just a load_state_dict into it) must be the one the next
+    forward reads and updates."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd.network import xception as X
+    net = X.xception(pretrained=False).cuda().train()
+    x = torch.randn(2, 3, 96, 96, device='cuda')
+    y0 = net.low_level_features(x)
+    assert int(net.bn1.num_batches_tracked) == 1
+    old = net.bn1
+    new = torch.nn.BatchNorm2d(32).cuda().train()
+    with torch.no_grad():
+        new.weight.fill_(0.5)
+    net.bn1 = new
+    y1 = net.low_level_features(x)
+    assert int(new.num_batches_tracked) == 1 and int(old.num_batches_tracked) == 1
+    assert not torch.equal(y0, y1)                       # the new gain reached the kernels
+    with torch.no_grad():
+        net.bn1.weight.fill_(1.0)
+    y2 = net.low_level_features(x)                       # same values as the first forward: same bits
+    assert torch.equal(y2, y0) and int(new.num_batches_tracked) == 2
