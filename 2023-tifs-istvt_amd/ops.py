@@ -161,6 +161,7 @@ def refresh_stale_operands() -> int:
     of a forward pass; without it the same work happens lazily, one launch per weight (84 per step at depth 12, each far
     shorter than the ~5 us a launch occupies the queue for).  Returns the number of weights re-cast."""
     import ctypes as C
+    _refresh_derived()
     todo = []
     for key, (refs, out, wt) in list(_operands.items()):
         ws = [r() for r in refs]
@@ -209,6 +210,38 @@ def refresh_stale_operands() -> int:
     for key, ws, out, wt, ver, hit in todo:
         _wcache[key] = (hit[0], ver, out)
     return n
+
+# ------------------------------------------------------------------------------------------
+# Derived weight layouts that are built with a few torch ops (the stem's tap-major depthwise weights, conv1 / conv2 in
+# GEMM form): cached per parameter version like the operand copies, and -- like them -- rebuilt by
+# refresh_stale_operands(), i.e. right behind the optimizer step when a fused optimizer drives the loop, instead of at
+# the head of the next forward pass (where a loop that syncs every step has the GPU waiting for the host).
+_derived: dict = {}
+
+
+def derived(key, w: Tensor, builder):
+    """builder(w) -> Tensor, cached until `w` changes (its version counter, or a raw-pointer writer's epoch)"""
+    hit = _derived.get(key)
+    ver = _versions((w,))
+    if hit is not None and hit[0]() is w and hit[1] == ver:
+        return hit[2]
+    out = builder(w)
+    _derived[key] = (weakref.ref(w, lambda _r, k=key, c=_derived: c.pop(k, None)), ver, out, builder)
+    return out
+
+
+def _refresh_derived() -> int:
+    n = 0
+    for key, (ref, ver, _out, builder) in list(_derived.items()):
+        w = ref()
+        if w is None:
+            _derived.pop(key, None)
+        elif ver != _versions((w,)):
+            # a FRESH tensor (never in place): whatever a live graph still holds of the old layout stays intact
+            _derived[key] = (ref, _versions((w,)), builder(w), builder)
+            n += 1
+    return n
+
 
 G256_MIN = 64          # smallest output edge routed to the 256x256 DMA GEMM (mirrors ISTVT_G256_MIN in gemm.hip)
 

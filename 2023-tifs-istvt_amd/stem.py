@@ -198,27 +198,21 @@ def dwconv_wgrad(x: Tensor, dout: Tensor, Fr: int, H: int, W: int, C: int, in_bn
 
 def tap_major(w: Tensor) -> Tensor:
     """depthwise weight (C, 1, 3, 3) -> float32 [9][C] (the layout istvt_dwconv3x3 takes), cached until the parameter
-    changes (one small strided copy per weight per step otherwise)"""
-    key = (id(w), 'tap')
-    hit = ops._wcache.get(key)
-    ver = ops._versions((w,))
-    if hit is not None and hit[0]() is w and hit[1] == ver:
-        return hit[2]
-    out = w.detach().reshape(w.shape[0], 9).t().contiguous()
-    import weakref
-    ops._wcache[key] = (weakref.ref(w, lambda _r, k=key, c=ops._wcache: c.pop(k, None)), ver, out)
-    return out
+    changes and rebuilt behind the optimizer step (ops.derived)"""
+    return ops.derived((id(w), 'tap'), w, lambda q: q.detach().reshape(q.shape[0], 9).t().contiguous())
 
 
 def _conv1_weight(w: Tensor, dtype) -> Tensor:
     """(32,3,3,3) [co][ci][dy][dx] -> [co][(dy,dx,ci) padded to 32] in the compute dtype."""
-    w2 = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 27)
-    w2 = torch.nn.functional.pad(w2, (0, 5))
-    return ops.cast(w2.contiguous(), dtype)
+    def build(q):
+        w2 = q.detach().permute(0, 2, 3, 1).reshape(q.shape[0], 27)
+        return ops.cast(torch.nn.functional.pad(w2, (0, 5)).contiguous(), dtype)
+    return ops.derived((id(w), 'conv1', dtype), w, build)
 
 
 def _conv2_weight(w: Tensor, dtype) -> Tensor:
-    return ops.cast(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous(), dtype)
+    return ops.derived((id(w), 'conv2', dtype), w,
+                       lambda q: ops.cast(q.detach().permute(0, 2, 3, 1).reshape(q.shape[0], -1).contiguous(), dtype))
 
 
 # ------------------------------------------------------------------------------------------ the Function
