@@ -652,6 +652,15 @@ def headline(a, world, rank, local_rank, multi):
                  'collective_cost_ms_per_step': round((elapsed - max(ts)) / a.steps * 1e3, 3),
                  'note': 'every rank runs the same K steps without any collective, all ranks at once; headline ms_per_step '
                          'minus this = what the all-reduce (and its overlap losses) costs per step'}
+        # those steps applied rank-local gradients: put every rank back on rank 0's weights and optimizer state, so that the
+        # legs that follow all-reduce gradients of ONE model again (timing does not care; the numbers should still mean something)
+        if bucket.flat_params is not None:
+            dist.broadcast(bucket.flat_params, 0)
+            for name in getattr(opt, '_state_names', ()):
+                dist.broadcast(getattr(opt, name), 0)
+            ops.invalidate_weight_cache()
+        else:
+            parallel.broadcast_parameters(model)
         if was_early:
             bucket.enable_early_all_reduce(first_vit)
 
