@@ -496,3 +496,32 @@ def test_host_scalar_passes_host_tensors_through(pkg):
     assert h.item() == 1.5 and float(h) == 1.5 and int(parallel.HostScalar(torch.tensor(3))) == 3
     with pytest.raises(ValueError):
         parallel.HostScalar(torch.zeros(3))
+
+
+def test_derived_weight_layouts_follow_the_parameter(pkg):
+    """ops.derived: a layout built from a parameter with a few torch ops is cached until the parameter changes (version
+    counter or a raw-pointer writer's epoch), rebuilt as a FRESH tensor by the operand refresh (what a live graph holds of
+    the old one stays intact), and dropped when the parameter dies."""
+    import gc
+    from istvt_amd import ops
+    w = torch.nn.Parameter(torch.arange(12.0).reshape(3, 4))
+    calls = []
+
+    def build(q):
+        calls.append(1)
+        return q.detach().t().contiguous()
+    key = (id(w), 'test-layout')
+    a = ops.derived(key, w, build)
+    assert ops.derived(key, w, build) is a and len(calls) == 1
+    with torch.no_grad():
+        w.mul_(2.0)                                         # an optimizer step: the version counter moves
+    held = a.clone()
+    ops._refresh_derived()                                  # (what refresh_stale_operands() runs first)
+    b = ops.derived(key, w, build)
+    assert b is not a and len(calls) == 2 and torch.equal(b, w.detach().t()) and torch.equal(a, held)
+    ops.invalidate_weight_cache()                           # a kernel wrote the parameter through a raw pointer
+    c = ops.derived(key, w, build)
+    assert c is not b and len(calls) == 3
+    del w
+    gc.collect()
+    assert key not in ops._derived
