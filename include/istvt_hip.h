@@ -21,9 +21,12 @@
  *     ordered (clip b, frame f, token p); stem activations are NHWC [frames][H][W][C].
  *   - `ld*` arguments are row strides in ELEMENTS (>= the row width, multiples of 8).  The host
  *     keeps transformer activations and the bf16 GEMM operand copies of the weights with rows
- *     padded to a multiple of 64 elements (728 -> 768, 2912 -> 2944) so that every row starts on
- *     a 128-byte line: the LDS-DMA staging of the GEMMs is priced per cache line touched
- *     (tools/dma_probe.hip).  Pad columns are never read as data and never written.
+ *     padded so that every row starts on a 128-byte line and spans an ODD number of lines
+ *     (ops.pad_ld: 728 -> 832, 2912 -> 3008, 512 -> 576, 1536 -> 1600 elements): the LDS-DMA
+ *     staging of the GEMMs is priced per cache line touched (tools/dma_probe.hip), and with an
+ *     even line count the rows of a column panel fall on half of the memory channels.  The
+ *     kernels only require 16-byte aligned rows; pad columns are never read as data and never
+ *     written.
  */
 #ifndef ISTVT_HIP_H
 #define ISTVT_HIP_H

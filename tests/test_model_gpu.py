@@ -424,10 +424,10 @@ def test_g6_fullwidth_bf16_vs_reference_golden(golden_dir):
 
 
 def test_g5_native_bf16_vs_reference_golden(golden_dir):
-    """G5 (the reference-native model: T=6, 300^2, depth 12) run in bfloat16 against the reference's capture: logit,
-    loss and the transformer's gradient norms.  The recipe's sin-wave stem weights make the BatchNorm chain amplify
-    rounding ~2x per layer (DESIGN.md "Parity"), so the stem's own bf16 gradients are judged with well-conditioned
-    weights in test_depth12_bf16_vs_oracle below."""
+    """G5 (the reference-native model: T=6, 300^2, depth 12) run in bfloat16 against the reference's capture: logit, the
+    set of live gradients and their finiteness.  The fixture is SATURATED (sin-wave weights, temporal scores ~50): its
+    gradient values are judged in float32 (test_g5_native_end_to_end_hip); bfloat16 gradients are judged on the
+    well-conditioned reference captures G5c / G6c."""
     XceptionVidTr, model_selection = _load()
     g = np.load(os.path.join(golden_dir, 'G5_native.npz'))
     model = load_recipe(XceptionVidTr(compute_dtype=torch.bfloat16))
@@ -444,22 +444,11 @@ def test_g5_native_bf16_vs_reference_golden(golden_dir):
     live = [str(s) for s in g['live_param_names']]
     assert sorted(k for k, p in named.items() if p.grad is not None) == sorted(live)
     assert all(torch.isfinite(named[k].grad).all() for k in live)
-    # Gradient norms against the reference's 252 captured ones.  What bfloat16 can promise on THIS
-    # fixture is limited -- measured on MI355X (round 4, tmp script g5bf16.py): the head and the final LayerNorm 0.877 of
-    # the reference norm (the logit itself is 3 % off and the loss gradient follows), the feed-forward and spatial-attention
-    # weights 0.28 ... 2.3, the temporal block 0.002 ... 813 (to_qk) and its LayerNorm 0.1 ... 46: the recipe's
-    # sin-wave weights drive the temporal scores to ~50, where one bf16 rounding of a score moves a probability by a
-    # factor, and every layer below inherits it.  So: tight where the model is well-conditioned, a factor where it is
-    # not, nothing for the temporal block -- whose bf16 gradients are held to cosine > 0.97 / norms within 15 % on
-    # well-conditioned weights by test_depth12_fp32_and_bf16_vs_oracle, the configuration bench.py runs.
-    ratio = {k: float(named[k].grad.float().norm()) / float(g['gnorm.' + k]) for k in live if float(g['gnorm.' + k]) > 0}
-    for k, r in ratio.items():
-        if k.startswith(('vit.mlp_head', 'vit.transformer.norm')):
-            assert 0.75 < r < 1.25, (k, r)
-        elif '.1.fn.' in k or '.2.fn.' in k:             # spatial attention and feed-forward weights of every layer
-            assert 0.2 < r < 3.0, (k, r)
-        elif k.startswith('xcep.'):
-            assert 0.12 < r < 1.2, (k, r)
+    # Gradient VALUES are not judged on this fixture (round 6): its sin-wave weights drive the temporal scores to ~50, where
+    # one bf16 rounding of a score moves a probability by a factor (the temporal block's gradient norms ranged over
+    # 0.002 ... 813 x the reference's).  Every live tensor -- the temporal block's to_qk / to_v included -- is held to the
+    # reference's own vectors by direction and norm on the well-conditioned captures G5c / G6c
+    # (test_g5c_native_conditioned_hip[bf16], test_g6c_fullwidth_conditioned_hip[bf16]).
 
 
 def _bucket_grads(model):
