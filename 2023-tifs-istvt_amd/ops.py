@@ -123,7 +123,21 @@ def _holders(t: Tensor) -> tuple:
     """(Python references, C++ references to the TensorImpl -- autograd SavedVariables --, tensors sharing the storage --
     views and slices) of `t`, each including what THIS call adds.  Only differences between two calls made the same way
     mean anything: _operand_holders() is the one place that calls it."""
-    return (sys.getrefcount(t), t._use_count(), torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+    try:
+        return (sys.getrefcount(t), t._use_count(), torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+    except AttributeError:
+        # private torch APIs (Tensor._use_count, torch._C._storage_Use_Count) gone in this build: report "held by somebody",
+        # so that no operand is ever rewritten in place (it is re-made instead: correct, one launch per weight slower)
+        global _holders_warned
+        if not _holders_warned:
+            _holders_warned = True
+            import warnings
+            warnings.warn('istvt_amd.ops: torch lacks the reference-count introspection used to refresh bf16 operand copies in '
+                          'place; falling back to re-making them (slower, still correct)')
+        return (1 << 30, 1 << 30, 1 << 30)
+
+
+_holders_warned = False
 
 
 def _operand_holders(key) -> tuple:
@@ -140,7 +154,15 @@ def _idle_holder_counts(view: bool) -> tuple:
         try:
             key = ('calibration', view)
             mk = (lambda: torch.empty((2, 16))[:, :8]) if view else (lambda: torch.empty((2, 8)))
-            out, wt = mk(), mk()
+            # Under the mode real operands are made in (a normal forward): the first stale refresh now runs inside the
+            # optimizer step, possibly under torch.inference_mode() / no_grad, where a slice carries no ._base and its storage
+            # has one holder fewer -- a baseline taken there made every later refresh look "held" and silently fell back to 84
+            # lazy casts per step.
+            with torch.inference_mode(False), torch.enable_grad():
+                out, wt = mk(), mk()
+            if (out._base is not None) != bool(view) or (wt._base is not None) != bool(view):
+                raise RuntimeError('istvt_amd.ops: calibration operand is %sa view (expected view=%r)'
+                                   % ('' if out._base is not None else 'not ', view))
             _operands[key] = ((), out, wt)
             _wcache[key] = (None, None, out)
             _wcache[(id(out), 'T')] = (None, 0, wt)

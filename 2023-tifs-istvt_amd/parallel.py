@@ -320,7 +320,13 @@ class _FusedOptimizer(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         if set_to_none:
             raise ValueError('gradients are views of the flat bucket: they cannot be set to None')
-        if not (self.fused_zero_grad and self.steps > 0):
+        # A backward pass that aborted behind the grad-ready hook leaves an early all-reduce nobody collected (and the CU
+        # reserve raised): it is waited for and dropped HERE, on every call -- the fused step's re-zeroing skips
+        # bucket.zero(), which used to be the only way to reach this recovery -- and the half-reduced bucket of
+        # such a step is really zeroed.
+        aborted = self.bucket._early_work is not None
+        self.bucket._drop_early_work()
+        if aborted or not (self.fused_zero_grad and self.steps > 0):
             self.bucket.zero()
 
     def _done(self):

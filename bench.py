@@ -84,8 +84,11 @@ def parse():
                          'timed region (train_CNN.py:506,512,534-536): per-step H2D copy of the (B,T,3,S,S) batch from pinned '
                          'memory (double-buffered on a copy stream), loss.item() and the accuracy count; NOT the headline value')
     ap.add_argument('--no-host-boundary', dest='host_boundary', action='store_false', help='skip the with_host_boundary leg')
-    ap.add_argument('--keep-schedule', action='store_true',
-                    help='N > 1: report the default (early, two-piece) all-reduce schedule even if the single blocking one measured faster')
+    ap.add_argument('--keep-schedule', action='store_true', default=True,
+                    help='(default since round 6) N > 1: the headline is the schedule of the FIRST timed block -- the early, '
+                         'two-piece all-reduce unless --no-early-allreduce -- and the other schedule is reported as an extra')
+    ap.add_argument('--auto-schedule', dest='keep_schedule', action='store_false',
+                    help='N > 1: let the headline be whichever of the two all-reduce schedules measured faster (rounds 4-5 behaviour)')
     ap.add_argument('--rccl-rehearsal', action='store_true',
                     help='N = 1 only: initialise an RCCL ("nccl") process group of ONE rank and run every collective of the '
                          'N > 1 path anyway (ISTVT_FORCE_COLLECTIVES=1: parameter broadcast, the early asynchronous '
@@ -432,31 +435,59 @@ def other_configs(a, local_rank, steps=10, warmup=5):
     return res
 
 
-N1_CACHE = [os.path.join(ROOT, 'gpurun_out', 'istvt_bench_n1.json'), '/tmp/istvt_bench_n1.json']
+def _n1_cache_paths():
+    """per-user locations only (never a fixed name in world-writable /tmp): the repo's gpurun_out/ and $XDG_CACHE_HOME"""
+    cache = os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache')
+    return [os.path.join(ROOT, 'gpurun_out', 'istvt_bench_n1.json'), os.path.join(cache, 'istvt_amd', 'istvt_bench_n1.json')]
+
+
+N1_MAX_AGE_S = 6 * 3600
+
+
+def _code_rev():
+    """what the record is tied to: sha256 of bench.py + the library (a stale record of other code must not be embedded)"""
+    import hashlib
+    h = hashlib.sha256()
+    for path in (os.path.abspath(__file__), os.path.join(ROOT, '2023-tifs-istvt_amd', 'libistvt_hip.so')):
+        try:
+            with open(path, 'rb') as fh:
+                h.update(fh.read())
+        except OSError:
+            h.update(b'missing')
+    return h.hexdigest()[:16]
 
 
 def n1_cache_write(out):
     """the N = 1 headline (value, ms per step, cpu_baseline) where a later N > 1 run on the same node finds it"""
     rec = {'value': out['value'], 'unit': out['unit'], 'ms_per_step': out['ms_per_step'], 'workload': out['config']['workload'],
-           'cpu_baseline': out.get('cpu_baseline'), 'written_unix': int(time.time()), 'host': os.uname().nodename}
-    for path in N1_CACHE:
+           'cpu_baseline': out.get('cpu_baseline'), 'written_unix': int(time.time()), 'host': os.uname().nodename,
+           'uid': os.getuid(), 'code_rev': _code_rev(), 'config': out['config']}
+    for path in _n1_cache_paths():
         try:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            with open(path, 'w') as fh:
+            os.makedirs(os.path.dirname(path), mode=0o700, exist_ok=True)
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, 'w') as fh:
                 json.dump(rec, fh)
         except OSError:
             pass
 
 
-def n1_cache_read():
-    best = None
-    for path in N1_CACHE:
+def n1_cache_read(workload=None):
+    """the newest record of THIS host, user and code revision (and workload, if given) that is younger than N1_MAX_AGE_S"""
+    best, rev = None, _code_rev()
+    for path in _n1_cache_paths():
         try:
-            with open(path) as fh:
+            fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+            with os.fdopen(fd) as fh:
+                if os.fstat(fh.fileno()).st_uid != os.getuid():
+                    continue
                 rec = json.load(fh)
-            if rec.get('host') == os.uname().nodename and (best is None or rec['written_unix'] > best['written_unix']):
+            if (rec.get('host') == os.uname().nodename and rec.get('uid') == os.getuid() and rec.get('code_rev') == rev
+                    and (workload is None or rec.get('workload') == workload)
+                    and 0 <= int(time.time()) - rec['written_unix'] <= N1_MAX_AGE_S
+                    and (best is None or rec['written_unix'] > best['written_unix'])):
                 best = rec
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, TypeError):
             pass
     if best is not None:
         best['age_s'] = int(time.time()) - best['written_unix']
@@ -617,9 +648,10 @@ def headline(a, world, rank, local_rank, multi):
         ts = timed(a.steps)
         schedules[other] = {'ms_per_step': round(max(ts) / a.steps * 1e3, 3),
                             'per_rank_ms_per_step': [round(t / a.steps * 1e3, 3) for t in ts], 'headline': False}
-        # The line's `value` is the schedule that ran faster here (both are the complete data-parallel step, each timed
-        # over the same K steps after warm-up, max over ranks; a schedule named on the command line is kept): the overlap
-        # of the early all-reduce with the stem backward has never run on real links, and a job would pick the same way.
+        # The line's `value` is the FIRST timed block's schedule (round 6, VERDICT r5 item 6: the headline must not flip
+        # schedules silently, so that `collectives_per_step` of a SCALE record is what the line says); the other schedule
+        # is an extra.  --auto-schedule restores "whichever ran faster" (both are the complete data-parallel step, each
+        # timed over the same K steps after warm-up, max over ranks).
         if not (a.no_early_allreduce or a.keep_schedule) and max(ts) < elapsed:
             schedules[first]['headline'], schedules[other]['headline'] = False, True
             elapsed = max(ts)
@@ -656,11 +688,20 @@ def headline(a, world, rank, local_rank, multi):
         # legs that follow all-reduce gradients of ONE model again (timing does not care; the numbers should still mean something)
         if bucket.flat_params is not None:
             dist.broadcast(bucket.flat_params, 0)
-            for name in getattr(opt, '_state_names', ()):
-                dist.broadcast(getattr(opt, name), 0)
             ops.invalidate_weight_cache()
         else:
             parallel.broadcast_parameters(model)
+        if getattr(opt, '_state_names', None):
+            for name in opt._state_names:
+                dist.broadcast(getattr(opt, name), 0)
+        else:                               # torch.optim.SGD / AdamW (--torch-optimizer): momentum / moments are rank-local too
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        dist.broadcast(v, 0)
+        for buf in model.buffers():         # BatchNorm running statistics / counters follow rank 0 as well
+            if buf.is_cuda:
+                dist.broadcast(buf, 0)
         if was_early:
             bucket.enable_early_all_reduce(first_vit)
 
@@ -897,7 +938,9 @@ def headline(a, world, rank, local_rank, multi):
                                   'scale_folded_into_optimizer': bool(bucket.defer_scale),
                                   'rccl_rehearsal': bool(a.rccl_rehearsal),
                                   'collectives_per_step': 1 if (a.no_early_allreduce or bool(schedules and schedules.get('single_blocking_allreduce', {}).get('headline'))) else 2,
-                                  'headline_rule': 'the faster of the two schedules, each timed over the same K steps (max over ranks); --keep-schedule / --no-early-allreduce pin one',
+                                  'headline_rule': ('the schedule of the first timed block (the other one is the extra under `schedules`); --no-early-allreduce makes '
+                                                    "north_star's single blocking all-reduce the first block, --auto-schedule reports the faster of the two") if a.keep_schedule
+                                  else 'the faster of the two schedules, each timed over the same K steps (max over ranks)',
                                   'cu_reserve_during_early_allreduce': bucket.cu_reserve,
                                   'schedules': schedules, 'without_collectives': alone}
         ms = torch.cuda.memory_stats(dev)
@@ -982,8 +1025,15 @@ def main():
         if world > 1:
             # cpu_baseline is measured at N = 1 only (bounded sample on rank 0); the N > 1 line carries the newest N = 1
             # record of this host, if a run left one, so SCALE can be cross-checked against BENCH from one line
-            out['n1_reference'] = n1_cache_read() or {'note': 'no N=1 run of this host on record (run `python bench.py` first); '
-                                                             'see distributed.without_collectives for the same-job figure'}
+            ref = n1_cache_read()
+            out['n1_reference'] = ref or {'note': 'no N=1 run of this host, user and code revision on record; cpu_baseline was '
+                                                  'measured by rank 0 of this job instead; see distributed.without_collectives '
+                                                  'for the same-job single-GPU figure'}
+            if (ref is None or not ref.get('cpu_baseline')) and not a.no_cpu_baseline and not a.eval:
+                # a fresh 8-GPU node: the line is self-contained (the bounded sample, rank 0 only, after the timed region; the
+                # other ranks wait in the closing barrier)
+                out['cpu_baseline'] = cpu_baseline(a.frames, a.size, a.depth)
+                out['cpu_baseline']['note'] = 'measured by rank 0 of this N > 1 job (no N = 1 record on this node)'
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

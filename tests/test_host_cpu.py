@@ -470,24 +470,38 @@ def test_cu_reserve_is_a_launch_argument_not_library_state(pkg):
 
 def test_bench_n1_record_round_trip(tmp_path, monkeypatch):
     """the N = 1 headline record a default run leaves for a later N > 1 run on the same host (bench.n1_cache_write / _read):
-    newest record of THIS host wins, unreadable or foreign files are ignored"""
+    newest record of THIS host, user and code revision wins; unreadable, foreign, stale, other-revision records and symlinks
+    are ignored (no fixed name in /tmp, O_NOFOLLOW, revision + configuration in the record, bounded age)"""
     import importlib
+    import json as _json
     bench = importlib.import_module('bench')
     a, b = str(tmp_path / 'a' / 'n1.json'), str(tmp_path / 'b.json')
-    monkeypatch.setattr(bench, 'N1_CACHE', [a, b])
+    assert not any(os.path.dirname(p) == '/tmp' for p in bench._n1_cache_paths())     # no fixed name in world-writable /tmp
+    monkeypatch.setattr(bench, '_n1_cache_paths', lambda: [a, b])
     assert bench.n1_cache_read() is None
     out = {'value': 609.0, 'unit': 'clips/s', 'ms_per_step': 52.5, 'config': {'workload': 'C2: ...'},
            'cpu_baseline': {'value': 0.67, 'cores': 32, 'kind': 'port'}}
     bench.n1_cache_write(out)
     rec = bench.n1_cache_read()
     assert rec['value'] == 609.0 and rec['cpu_baseline']['value'] == 0.67 and rec['age_s'] >= 0 and rec['host'] == os.uname().nodename
-    import json as _json
+    assert rec['code_rev'] == bench._code_rev() and rec['config'] == out['config'] and rec['uid'] == os.getuid()
+    assert oct(os.stat(a).st_mode & 0o777) == '0o600'
+    assert bench.n1_cache_read(workload='C2: ...')['value'] == 609.0 and bench.n1_cache_read(workload='C4') is None
     with open(b, 'w') as fh:                                # a record of another host: ignored
         _json.dump(dict(rec, host='elsewhere', written_unix=rec['written_unix'] + 100, value=1.0), fh)
     assert bench.n1_cache_read()['value'] == 609.0
+    with open(b, 'w') as fh:                                # another code revision: ignored
+        _json.dump(dict(rec, code_rev='0' * 16, written_unix=rec['written_unix'] + 100, value=2.0), fh)
+    assert bench.n1_cache_read()['value'] == 609.0
+    with open(b, 'w') as fh:                                # too old: ignored
+        _json.dump(dict(rec, written_unix=rec['written_unix'] - bench.N1_MAX_AGE_S - 10, value=3.0), fh)
+    assert bench.n1_cache_read()['value'] == 609.0
+    os.remove(b)
+    os.symlink(a, b)                                        # a symlink is never followed (and a is still valid)
+    assert bench.n1_cache_read()['value'] == 609.0
     with open(a, 'w') as fh:
         fh.write('not json')
-    assert bench.n1_cache_read() is None                    # a: unreadable, b: foreign
+    assert bench.n1_cache_read() is None                    # a: unreadable, b: a symlink
 
 
 def test_host_scalar_passes_host_tensors_through(pkg):
@@ -525,3 +539,41 @@ def test_derived_weight_layouts_follow_the_parameter(pkg):
     del w
     gc.collect()
     assert key not in ops._derived
+
+
+def test_fused_zero_grad_recovers_from_an_aborted_backward(pkg):
+    """the recovery from a backward that aborted behind the grad-ready hook (orphaned early all-reduce, CU
+    reserve raised) must be reachable from the DEFAULT loop, where the fused step re-zeroes and zero_grad() skips
+    bucket.zero()."""
+    import types
+    from istvt_amd import parallel
+    p = torch.nn.Parameter(torch.zeros(4))
+    b = parallel.GradBucket([p], fuse_accumulate=True)
+
+    class Work:
+        waited = False
+
+        def wait(self):
+            self.waited = True
+
+    w = Work()
+    b._early_work = (w, 0)
+    b.flat.fill_(3.0)
+    opt = types.SimpleNamespace(bucket=b, fused_zero_grad=True, steps=5)
+    parallel._FusedOptimizer.zero_grad(opt)
+    assert w.waited and b._early_work is None and float(b.flat.abs().sum()) == 0.0      # dropped AND really zeroed
+    b.flat.fill_(3.0)
+    parallel._FusedOptimizer.zero_grad(opt)                                             # the normal loop: no zero pass
+    assert float(b.flat.sum()) == 12.0
+
+
+def test_operand_refresh_baseline_is_mode_independent(pkg):
+    """the idle-holder baseline of ops.refresh_stale_operands() is taken under grad mode whatever mode the first
+    stale refresh runs in (the optimizer step: possibly torch.inference_mode())."""
+    from istvt_amd import ops
+    ops._idle_counts.clear()
+    with torch.inference_mode():
+        a = (ops._idle_holder_counts(True), ops._idle_holder_counts(False))
+    ops._idle_counts.clear()
+    b = (ops._idle_holder_counts(True), ops._idle_holder_counts(False))
+    assert a == b

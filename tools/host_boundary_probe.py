@@ -68,6 +68,9 @@ def run(n, h2d, item, acc):
         if h2d:
             torch.cuda.current_stream(dev).wait_event(ready[i % 2])
             if i + 1 < n:
+                # upload(i + 1) overwrites dbuf[(i - 1) % 2]: step i - 1's backward (conv1 weight gradient) may still be
+                # reading it when no .item() drained the stream (the no-drain variants raced) -- as bench.py does
+                copy_stream.wait_stream(torch.cuda.current_stream(dev))
                 upload(i + 1)
         opt.zero_grad()
         logits = model(dbuf[i % 2])
