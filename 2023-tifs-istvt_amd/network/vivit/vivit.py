@@ -6,6 +6,8 @@ Geometry the reference hard-codes is exposed as keyword arguments whose defaults
 selects float32 (parity mode, default) or bfloat16 (throughput mode) activation storage;
 parameters stay float32 so reference checkpoints load unchanged (state-dict names identical).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -148,6 +150,9 @@ class XceptionVidTr(nn.Module):
                          scale_dim=scale_dim, compute_dtype=compute_dtype)
         self.compute_dtype = compute_dtype
         self.set_attn_fp8(attn_fp8)
+        self._step_graphs = None
+        if os.environ.get('ISTVT_STEP_GRAPHS', '0') == '1':
+            self.enable_step_graphs(True)
 
     def set_attn_fp8(self, on=True):
         """fp8 (OCP e4m3) operands in the spatial-attention MFMAs (BASELINE.json configs[4]); needs bfloat16 compute."""
@@ -168,7 +173,25 @@ class XceptionVidTr(nn.Module):
         self.vit.transformer.dead_row_elimination = bool(on)
         return self
 
+    def enable_step_graphs(self, on=True, warmup=2):
+        """Replay the training forward and backward as two captured HIP graphs instead of ~1 400 launches issued from Python
+        (istvt_amd.parallel.StepGraphs: preconditions, fall-backs and the address contract).  The caller's loop does not
+        change: ``model(x)`` returns logits inside its autograd graph, ``loss.backward()`` replays the backward graph.
+        Also switched on by ISTVT_STEP_GRAPHS=1 at construction."""
+        if on:
+            from istvt_amd import parallel
+            self._step_graphs = parallel.StepGraphs(self, self._forward_eager, warmup=warmup)
+        else:
+            self._step_graphs = None
+        return self
+
     def forward(self, x):
+        g = self._step_graphs
+        if g is not None:
+            return g(x)
+        return self._forward_eager(x)
+
+    def _forward_eager(self, x):
         b, t = x.shape[:2]
         feats = self.xcep.model.low_level_features_nhwc(x.flatten(0, 1), self.compute_dtype)   # (b*t, h, w, c)
         n, h, w, c = feats.shape

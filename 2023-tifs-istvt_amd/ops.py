@@ -184,6 +184,8 @@ def refresh_stale_operands() -> int:
     shorter than the ~5 us a launch occupies the queue for).  Returns the number of weights re-cast."""
     import ctypes as C
     _refresh_derived()
+    if _static[0]:
+        _refresh_plain_copies()
     todo = []
     for key, (refs, out, wt) in list(_operands.items()):
         ws = [r() for r in refs]
@@ -203,7 +205,7 @@ def refresh_stale_operands() -> int:
             del out, wt, hit
             idle = (_idle_holder_counts(_operands[key][1]._base is not None)[:3]
                     + _idle_holder_counts(_operands[key][2]._base is not None)[3:])
-            if any(a > b for a, b in zip(_operand_holders(key), idle)):
+            if not _static[0] and any(a > b for a, b in zip(_operand_holders(key), idle)):
                 _refs, out, _wt = _operands[key]
                 _operands.pop(key, None)
                 _wcache.pop(key, None)
@@ -259,9 +261,61 @@ def _refresh_derived() -> int:
         if w is None:
             _derived.pop(key, None)
         elif ver != _versions((w,)):
-            # a FRESH tensor (never in place): whatever a live graph still holds of the old layout stays intact
-            _derived[key] = (ref, _versions((w,)), builder(w), builder)
+            if _static[0]:
+                # captured HIP graphs hold the ADDRESS of the layout (parallel.StepGraphs): rebuilt in place
+                _out.copy_(builder(w))
+                _derived[key] = (ref, _versions((w,)), _out, builder)
+            else:
+                # a FRESH tensor (never in place): whatever a live autograd graph still holds of the old layout stays intact
+                _derived[key] = (ref, _versions((w,)), builder(w), builder)
             n += 1
+    return n
+
+
+# Static-address mode (parallel.StepGraphs: the forward / backward launch sequences captured as HIP graphs hold raw
+# pointers): every cached copy derived from a parameter -- bf16 operand pairs, plain casts, stacked operands, derived
+# layouts -- is then refreshed IN PLACE, always, by refresh_stale_operands(); nothing is ever re-made at a new address.
+# The price is the guarantee the eager mode gives a live autograd graph (its saved operand copies stay intact when the
+# parameter changes before backward): with graphs on, parameters must not be modified between a forward and its backward
+# -- which the graphs' own static activations forbid anyway.
+_static = [False]
+
+
+def set_static_addresses(on: bool) -> bool:
+    prev = _static[0]
+    _static[0] = bool(on)
+    return prev
+
+
+def _refresh_plain_copies() -> int:
+    """static-address mode: the cached copies that are NOT (operand, transpose) pairs of the grouped refresh -- plain casts
+    (weight_as without padding or of a narrow weight), padded casts without a fused transpose, stacked operands without one,
+    weight_t_as transposes, and the lazily made transposes of such copies (_transposed_operand) -- re-made into the buffers
+    they already live in.  A handful per model (the head's Linear, narrow 1x1 convolutions)."""
+    n = 0
+    for key, hit in list(_wcache.items()):
+        kind = key[1] if isinstance(key, tuple) and len(key) == 2 else None
+        if kind == 'T' or key in _operands:
+            continue                                    # transposes follow their source; pairs: the grouped refresh
+        refs, ver, out = hit
+        ws = [r() for r in (refs if isinstance(refs, tuple) else (refs,))]
+        if any(w is None for w in ws) or _versions(ws) == tuple(ver):
+            continue
+        if kind == 'cat':
+            r0 = 0
+            for w in ws:
+                out[r0:r0 + w.shape[0]].copy_(w.detach())
+                r0 += w.shape[0]
+        else:
+            w2 = ws[0].detach()
+            if w2.dim() != 2:
+                w2 = w2.reshape(w2.shape[0], -1)
+            out.copy_(w2.t() if kind == 't' else w2)    # casts on the way; `out` may be a row-padded view
+        tr = _wcache.get((id(out), 'T'))
+        if tr is not None and tr[0]() is out:
+            tr[2].copy_(out.t())
+        _wcache[key] = (refs, _versions(ws), out)
+        n += 1
     return n
 
 

@@ -438,3 +438,200 @@ class FusedAdamW(_FusedOptimizer):
                                           h['eps'], h['weight_decay'], self.steps + 1, int(self.fused_zero_grad),
                                           float(b.grad_scale), ops._stream()), 'istvt_adamw')
         self._done()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# HIP-graph replay of the training forward / backward (round 6)
+# ------------------------------------------------------------------------------------------------------------------------
+class _ReplayBackward(torch.autograd.Function):
+    """Puts a replayed forward graph's output into the caller's autograd graph: its backward copies the incoming gradient
+    into the static buffer and replays the captured backward graph (parameter gradients land in the flat bucket, as they
+    do when the kernels are launched one by one)."""
+
+    @staticmethod
+    def forward(ctx, anchor, entry, token):
+        ctx.entry = entry
+        ctx.token = token            # alive until this node has run its backward or has been dropped: StepGraphs' "pending" flag
+        return entry.static_out.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        entry, ctx.entry, ctx.token = ctx.entry, None, None
+        entry.static_gout.copy_(g)
+        entry.g_bwd.replay()
+        return None, None, None
+
+
+class _GraphEntry:
+    __slots__ = ('static_x', 'static_out', 'static_gout', 'g_fwd', 'g_bwd', 'keep', 'fingerprint', 'calls', 'pool')
+
+
+class StepGraphs:
+    """The launch sequences of ``model(x)`` and of its backward pass, captured once per (input shape, mode) as HIP graphs
+    (hipGraph via torch.cuda.CUDAGraph; the kernels are launched through the C ABI on torch's current stream, which is the
+    capturing stream inside ``torch.cuda.graph``) and replayed from then on: ~1 400 launches per training step at C2 become
+    two graph launches, the per-step host time falls from 14-23 ms of Python to ~3 ms, and a launch-bound configuration (C1,
+    small batches) runs at the speed of its kernels.
+
+    Transparent to the caller's loop (train_CNN.py:497-537 runs unchanged): ``model.enable_step_graphs()`` makes
+    ``model(x)`` return logits that are part of the caller's autograd graph; ``loss.backward()`` replays the backward graph.
+    A forward under ``torch.no_grad()`` (the validation loop, train_CNN.py:837-944) is a forward-only graph of its own.
+    Falls back to the launch-by-launch path whenever the preconditions do not hold:
+      * a CUDA input that does not require a gradient;
+      * with gradients enabled: every live parameter's gradient is a view of a ``GradBucket(fuse_accumulate=True)`` (the
+        kernels write the bucket directly; a torch optimizer's ``zero_grad(set_to_none=True)`` breaks that and is detected);
+      * no early all-reduce hook (N > 1 with the overlapped schedule stays launch-by-launch: the collective's handle is host state);
+      * no per-kernel instrumentation (bench.py's profiled step);
+      * the previous graphed forward of this entry has had its backward (or was dropped): an entry owns ONE set of saved
+        activations.
+    Addresses: parameters, gradients and every cached operand copy must stay where they were at capture; the cached copies are
+    refreshed in place (ops.set_static_addresses), parameters and gradients are fingerprinted (data_ptr of each) and a change
+    drops the graphs and captures again.  The first ``warmup`` calls of an entry run launch by launch (they fill the operand
+    caches, the statistics arena, the side stream, the kernels' one-time attribute calls).  Every entry has a memory pool of
+    its own: replaying one never touches what another saved for its backward."""
+
+    def __init__(self, model: torch.nn.Module, forward_eager, warmup: int = 2, max_entries: int = 4):
+        self.model = weakref.ref(model)
+        self.forward_eager = forward_eager
+        self.warmup = int(warmup)
+        self.max_entries = int(max_entries)
+        self.entries = {}
+        self.seen = {}
+        self.pending = {}               # entry key -> weakref to the token of a graphed forward whose backward has not run
+        self.anchor = None
+        self.live = None
+        self.stats = {'captures': 0, 'replays': 0, 'eager': 0, 'recaptures': 0}
+        self.last_reason = None
+
+    # -- preconditions -----------------------------------------------------------------------------------------------
+    def _live(self):
+        if self.live is None:
+            self.live = [p for _, p in live_named_parameters(self.model())]
+        return self.live
+
+    def _fingerprint(self, grads: bool):
+        fp = []
+        for p in self._live():
+            fp.append(p.data_ptr())
+            if grads:
+                g = p.grad
+                if g is None or not getattr(p, '_istvt_fused_grad', False):
+                    return None
+                fp.append(g.data_ptr())
+        return tuple(fp)
+
+    def why_not(self, x, key):
+        from . import functional as Fn
+        from . import ops
+        if self.model() is None:
+            return 'model gone'
+        if not x.is_cuda or x.requires_grad:
+            return 'input on the host or requiring a gradient'
+        if ops.kernel_profile is not None or ops.gemm_profile is not None:
+            return 'per-kernel instrumentation on'
+        if torch.cuda.is_current_stream_capturing():
+            return 'already inside a capture'
+        if key[-1]:                     # gradients enabled
+            if Fn.grad_ready_hooks:
+                return 'early all-reduce hook registered'
+            pend = self.pending.get(key)
+            if pend is not None and pend() is not None:
+                return 'a graphed forward is still waiting for its backward'
+        return None
+
+    # -- the call ----------------------------------------------------------------------------------------------------
+    def __call__(self, x):
+        from . import ops
+        m = self.model()
+        grads = torch.is_grad_enabled()
+        key = (tuple(x.shape), x.dtype, x.device.index, bool(m is not None and m.training), grads)
+        reason = self.why_not(x, key)
+        fp = None
+        if reason is None:
+            fp = self._fingerprint(grads)
+            if fp is None:
+                reason = 'a live gradient is not a fused-bucket view'
+        if reason is None:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if n < self.warmup:
+                reason = 'warm-up'
+            elif key not in self.entries and len(self.entries) >= self.max_entries:
+                reason = 'more (shape, mode) entries than max_entries'
+        if reason is not None:
+            self.last_reason = reason
+            self.stats['eager'] += 1
+            return self.forward_eager(x)
+        ent = self.entries.get(key)
+        if ent is not None and ent.fingerprint != fp:
+            # a parameter or gradient moved (a new bucket, load_state_dict into new storage, .to()): the captured pointers
+            # are dead -- drop every graph and start over
+            self.drop()
+            self.stats['recaptures'] += 1
+            ent = None
+        if ent is None:
+            ent = self._capture(x, key, fp, grads)
+        # operand copies the optimizer step (or a load_state_dict) made stale: in place, before the graph reads them
+        ops.refresh_stale_operands()
+        if ent.static_x.data_ptr() != x.data_ptr():
+            ent.static_x.copy_(x)
+        ent.g_fwd.replay()
+        ent.calls += 1
+        self.stats['replays'] += 1
+        if not grads:
+            return ent.static_out.detach().clone()
+
+        class _Token:
+            __slots__ = ('__weakref__',)
+        token = _Token()
+        self.pending[key] = weakref.ref(token)
+        return _ReplayBackward.apply(self.anchor, ent, token)
+
+    def _capture(self, x, key, fp, grads):
+        from . import functional as Fn
+        from . import ops
+        from . import stem as stem_mod
+        ops.set_static_addresses(True)
+        Fn.flush_stale_joins()
+        if self.anchor is None or self.anchor.device != x.device:
+            self.anchor = torch.zeros((), device=x.device, requires_grad=True)
+        ent = _GraphEntry()
+        ent.calls = 0
+        ent.fingerprint = fp
+        ent.static_x = x.detach().clone()
+        ent.static_gout = ent.g_bwd = None
+        ops.refresh_stale_operands()
+        ent.pool = torch.cuda.graph_pool_handle()
+        ent.g_fwd = torch.cuda.CUDAGraph()
+        with torch.set_grad_enabled(grads):
+            with torch.cuda.graph(ent.g_fwd, pool=ent.pool):
+                out = self.forward_eager(ent.static_x)
+            ent.static_out = out
+            if grads:
+                ent.static_gout = torch.zeros_like(out)
+                ent.g_bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ent.g_bwd, pool=ent.pool):
+                    # autograd.grad, not backward(): no AccumulateGrad node runs (those of the warm-up steps live on the
+                    # default stream, and the engine's stream hand-over to them is illegal inside a capture -- it crashed
+                    # the process); the kernels write the fused bucket themselves and the Functions return None for their
+                    # parameters
+                    got = torch.autograd.grad(out, self._live(), grad_outputs=ent.static_gout, allow_unused=True)
+                    # a Function that does hand a gradient tensor back is accumulated here, inside the capture, as
+                    # AccumulateGrad would have done
+                    for p, g in zip(self._live(), got):
+                        if g is not None:
+                            p.grad.add_(g)
+                del got
+        # everything outside the graphs' pool whose ADDRESS they captured stays alive with them
+        ent.keep = ([h[2] for h in ops._wcache.values()] + [d[2] for d in ops._derived.values()]
+                    + [stem_mod._arena.get('buf')] + [v[1:] for v in ops._operands.values()])
+        self.entries[key] = ent
+        self.stats['captures'] += 1
+        return ent
+
+    def drop(self):
+        """forget every captured graph (each entry's pool is released once the last reference is gone)"""
+        self.entries.clear()
+        self.seen.clear()
+        self.pending.clear()
+        self.live = None

@@ -480,6 +480,15 @@ class StemFn(Function):
             dx = torch.empty_like(sv['x'])
             _lib.check(L.istvt_col2im_conv1(dcol1.data_ptr(), dx.data_ptr(), Fr, S, dtc, _stream()), 'istvt_col2im_conv1')
         ctx.sv = None
+        # The two dense convolutions' weight gradients come out of a slab reduce as fresh tensors.  With the fused bucket they
+        # are added into .grad HERE instead of being handed to autograd: the same add, but no AccumulateGrad node takes part
+        # (inside a HIP-graph capture the engine's stream hand-over to an AccumulateGrad node created by an earlier,
+        # launch-by-launch step on the default stream is illegal -- parallel.StepGraphs).
+        for n in ('conv1.weight', 'conv2.weight'):
+            q = P[n]
+            if grads[n] is not None and getattr(q, '_istvt_fused_grad', False) and q.grad is not None:
+                q.grad.add_(grads[n].view(q.shape))
+                grads[n] = None
         out = [None if grads[n] is None else grads[n].view(P[n].shape) for n in param_names()]
         return (dx, None, None, None, *out)
 

@@ -110,6 +110,12 @@ def parse():
     ap.add_argument('--run_device', '-d', default=None,
                     help='train_CNN.py -d "0,1,...": that many devices.  The reference wraps the model in nn.DataParallel '
                          '(train_CNN.py:185-186); here it means one process per device (= --gpus N)')
+    ap.add_argument('--no-step-graphs', action='store_true',
+                    help='skip the with_step_graphs leg (the same K steps with the forward / backward replayed as two captured HIP '
+                         'graphs, parallel.StepGraphs, incl. the reference loop with loss.item() every step)')
+    ap.add_argument('--step-graphs', action='store_true',
+                    help='run the HEADLINE steps through the captured HIP graphs too (default: launch by launch; the graphs are '
+                         'reported as the extra field with_step_graphs)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short C4 / C5 / C1 legs that fill the other_configs field of the default run')
     ap.add_argument('--self-launch', action='store_true',
@@ -417,6 +423,21 @@ def other_configs(a, local_rank, steps=10, warmup=5):
                     'what': 'train-mode forward, no_grad' if forward_only else 'train step (fwd+bwd+fused SGD)',
                     'loss' if not forward_only else 'logit_sum': round(float(last.item()), 5),
                     'wall_s_incl_build': round(time.perf_counter() - t_build, 1)})
+        if forward_only or batch * frames <= 32:
+            # launch-bound legs: the same steps replayed as captured HIP graphs (parallel.StepGraphs)
+            model.enable_step_graphs(True)
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                last_g = step()
+            torch.cuda.synchronize(dev)
+            dtg = (time.perf_counter() - t0) / steps
+            rec['with_step_graphs'] = {'ms_per_step': round(dtg * 1e3, 3), 'clips_per_s': round(batch / dtg, 2),
+                                       'same_result': bool(float(last_g.item()) == float(last.item())) if forward_only else None,
+                                       'stats': dict(model._step_graphs.stats)}
+            model.enable_step_graphs(False)
         gf = GF_PER_CLIP_FWD_BWD.get(frames) if (size == 224 and depth == 12 and not forward_only) else None
         if (frames, size, depth, forward_only) == (6, 300, 12, False):
             gf = GF_PER_CLIP_NATIVE
@@ -566,6 +587,8 @@ def headline(a, world, rank, local_rank, multi):
         model.eval()
     if a.dead_row_elimination:
         model.set_dead_row_elimination(True)
+    if a.step_graphs:
+        model.enable_step_graphs(True)
 
     def step(reduce=True, xin=None, lab=None, want_logits=False, after_loss=None):
         xin = x if xin is None else xin
@@ -796,6 +819,34 @@ def headline(a, world, rank, local_rank, multi):
                                              '.item() on the launch stream, which drains the whole step): same values at '
                                              'the same program points (INTEGRATION.md: a two-line change of the loop)'}}
 
+    # ---- extra field: the same K steps with forward and backward replayed as two captured HIP graphs (parallel.StepGraphs)
+    graphs = None
+    if not (multi or a.eval or a.torch_optimizer or a.no_step_graphs or a.step_graphs):
+        model.enable_step_graphs(True)
+        for _ in range(4):                  # two launch-by-launch warm-up calls, the capture, one replay
+            step()
+        sync()
+        t1 = time.perf_counter()
+        step(); step()
+        t_enq_g = (time.perf_counter() - t1) / 2
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            loss_g = step()
+        sync()
+        e5 = time.perf_counter() - t1
+        graphs = {'ms_per_step': round(e5 / a.steps * 1e3, 3), 'clips_per_s': round(world * a.batch * a.steps / e5, 3),
+                  'host_enqueue_ms_per_step': round(t_enq_g * 1e3, 3), 'loss': round(float(loss_g.item()), 5),
+                  'stats': dict(model._step_graphs.stats),
+                  'note': 'model.enable_step_graphs(): forward and backward replayed as two captured HIP graphs (same kernels, '
+                          'same bits: tests/test_model_gpu.py::test_step_graphs_*); the caller\'s loop is unchanged; NOT the headline value'}
+        if hostb is not None:
+            e6, _res = hb_timed(False)
+            graphs['with_host_boundary_ms_per_step'] = round(e6 / a.steps * 1e3, 3)
+            graphs['with_host_boundary_note'] = ('the reference loop as written (H2D copy of the next batch, loss.item() and the '
+                                                 'accuracy count every step, train_CNN.py:506,512,534-536), no HostScalar')
+        model.enable_step_graphs(False)
+
     # ---- instrumented extra step: every GEMM launch bracketed by events on its stream
     roof = None
     kern = None
@@ -931,6 +982,9 @@ def headline(a, world, rank, local_rank, multi):
             out['with_dead_row_elimination'] = dre
         if hostb:
             out['with_host_boundary'] = hostb
+        if graphs:
+            out['with_step_graphs'] = graphs
+        out['config']['step_graphs'] = bool(a.step_graphs)
         if multi:
             out['distributed'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                   'per_rank_ms_per_step': per_rank,

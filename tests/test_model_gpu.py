@@ -1100,3 +1100,158 @@ def test_stem_owner_cache_follows_replaced_submodules():
         net.bn1.weight.fill_(1.0)
     y2 = net.low_level_features(x)                       # same values as the first forward: same bits
     assert torch.equal(y2, y0) and int(new.num_batches_tracked) == 2
+
+
+# ---- HIP-graph replay of the training step (round 6, parallel.StepGraphs) ---------------------------------------------
+def _graph_pair(dtype, T=4, side=139, depth=2, B=3, grid=9):
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import parallel
+    XceptionVidTr, _ = _load()
+    made = []
+    for graphs in (False, True):
+        torch.manual_seed(5)
+        model = XceptionVidTr(num_frames=T, grid=grid, depth=depth, compute_dtype=dtype).cuda().train()
+        live = [p for _, p in parallel.live_named_parameters(model)]
+        bucket = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=True)
+        opt = parallel.FusedSGD(bucket, lr=1e-2, momentum=0.9, zero_grad=True)
+        if graphs:
+            model.enable_step_graphs(True)
+        made.append((model, bucket, opt))
+    g = torch.Generator().manual_seed(6)
+    xs = [torch.randn((B, T, 3, side, side), generator=g).cuda() for _ in range(2)]
+    ys = [(torch.rand((B,), generator=g) > 0.5).float().cuda() for _ in range(2)]
+    return made, xs, ys
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_step_graphs_give_the_bits_of_the_launch_by_launch_loop(dtype):
+    """The reference's training loop as written (zero_grad -> forward -> BCE -> backward -> step, loss.item() every step,
+    train_CNN.py:497-537; the loss and logits of the previous iteration still alive when the next forward starts), once
+    launch by launch and once with model.enable_step_graphs(): the same logits at every step and the same flat parameter
+    buffer after 7 steps of SGD, bit for bit -- the captured graphs are the same kernels with the same arguments."""
+    made, xs, ys = _graph_pair(dtype)
+    crit = torch.nn.BCEWithLogitsLoss()
+    outs = []
+    for model, bucket, opt in made:
+        seq = []
+        for i in range(7):
+            opt.zero_grad()
+            logits = model(xs[i % 2])
+            loss = crit(logits.view(-1), ys[i % 2])
+            loss.backward()
+            opt.step()
+            seq.append((logits.detach().clone(), loss.item()))
+        torch.cuda.synchronize()
+        outs.append((seq, bucket.flat_params.detach().clone(),
+                     {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k}))
+    st = made[1][0]._step_graphs.stats
+    assert st['captures'] == 1 and st['replays'] == 5 and st['eager'] == 2, st
+    for (la, lossa), (lb, lossb) in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(la, lb) and lossa == lossb
+    assert torch.equal(outs[0][1], outs[1][1])
+    for k, v in outs[0][2].items():                         # BatchNorm running statistics and batch counters too
+        assert torch.equal(v, outs[1][2][k]), k
+
+
+def test_step_graphs_fall_back_and_recapture():
+    """what StepGraphs must NOT replay: a second forward while the first waits for its backward (an entry owns one set of
+    saved activations), a torch-style zero_grad(set_to_none=True) (the kernels' accumulate targets are gone), per-kernel
+    instrumentation; a forward under no_grad is a graph of its own (replaying it between a training forward and its backward
+    does not touch what that forward saved); moved gradients are noticed and captured again.  Every sequence is run on a
+    launch-by-launch twin from the same seed and must give the same bits."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import ops, parallel
+    made, xs, ys = _graph_pair(torch.bfloat16)
+    model, bucket, opt = made[1]
+    crit = torch.nn.BCEWithLogitsLoss()
+    g = model._step_graphs
+
+    def train_step(m, b, o, i=0):
+        o.zero_grad()
+        loss = crit(m(xs[i % 2]).view(-1), ys[i % 2])
+        loss.backward()
+        o.step()
+        return b.flat_params.clone()
+
+    def on_both(fn, *args, exact=True):
+        ra, rb = [fn(m, b, o, *args) for m, b, o in made]
+        same = torch.equal if exact else (lambda x, y: torch.allclose(x, y, rtol=1e-4, atol=1e-6))
+        assert all(same(x, y) for x, y in zip(ra, rb)) if isinstance(ra, (tuple, list)) else same(ra, rb)
+
+    def resync():
+        """the launch-by-launch twin takes over the graph model's parameters, optimizer state and BatchNorm buffers"""
+        (tm, tb, to), (gm, gb, go) = made
+        tb.flat_params.copy_(gb.flat_params)
+        for name in to._state_names:
+            getattr(to, name).copy_(getattr(go, name))
+        for (k, v), (_, w) in zip(tm.named_buffers(), gm.named_buffers()):
+            v.copy_(w)
+        ops.invalidate_weight_cache()
+    for i in range(4):
+        on_both(train_step, i)
+    assert g.stats['captures'] == 1 and g.stats['replays'] == 2
+
+    # (1) two forwards before one backward: the second runs launch by launch, the summed gradient is right
+    def two_forwards(m, b, o):
+        o.zero_grad()
+        l1 = m(xs[0])
+        l2 = m(xs[1])
+        (crit(l1.view(-1), ys[0]) + crit(l2.view(-1), ys[1])).backward()
+        grads = b.flat.clone()
+        o.step()
+        return grads
+    n_eager = g.stats['eager']
+    # (not bit for bit: with two forward passes in one backward the eager engine interleaves their nodes, so the grouped
+    #  weight-gradient launches are composed -- and their split-K sums ordered -- differently)
+    on_both(two_forwards, exact=False)
+    assert g.stats['eager'] == n_eager + 1 and g.last_reason == 'a graphed forward is still waiting for its backward'
+    resync()
+
+    # (2) no_grad forwards (train-mode statistics, as bench.py's C1 leg) around and BETWEEN a training forward and its backward
+    def with_no_grad(m, b, o):
+        o.zero_grad()
+        with torch.no_grad():
+            for _ in range(3):
+                m(xs[1])                                    # graphs: two warm-up calls, then capture + replay
+        lt = m(xs[0])
+        with torch.no_grad():
+            ev = m(xs[1])
+        crit(lt.view(-1), ys[0]).backward()
+        grads = b.flat.clone()
+        o.step()
+        return grads, ev
+    on_both(with_no_grad)
+    assert sum(1 for k in g.entries if not k[-1]) == 1 and sum(1 for k in g.entries if k[-1]) == 1
+
+    # (3) instrumentation on -> launch by launch
+    ops.kernel_profile = []
+    try:
+        n_eager = g.stats['eager']
+        train_step(model, bucket, opt)
+        assert g.stats['eager'] == n_eager + 1 and g.last_reason == 'per-kernel instrumentation on'
+    finally:
+        ops.kernel_profile = None
+    # (4) a torch-style zero_grad(set_to_none=True): not replayed
+    saved = [p.grad for p in bucket.params]
+    bucket.params[3].grad = None
+    n_eager = g.stats['eager']
+    out = model(xs[0])
+    del out
+    assert g.stats['eager'] == n_eager + 1 and g.last_reason == 'a live gradient is not a fused-bucket view'
+    for p, gr in zip(bucket.params, saved):
+        p.grad = gr
+    # (5) a new bucket (gradients and parameters at new addresses): noticed, captured again, still the launch-by-launch bits
+    n_cap = g.stats['captures']
+    for m, b, o in made:
+        live = [p for _, p in parallel.live_named_parameters(m)]
+        b2 = parallel.GradBucket(live, fuse_accumulate=True, flatten_params=True)
+        o2 = parallel.FusedSGD(b2, lr=1e-2, momentum=0.9, zero_grad=True)
+        m._twin = (b2, o2)
+    made[:] = [(m, m._twin[0], m._twin[1]) for m, _, _ in made]
+    # (the two models diverged in (3)/(4): put the twin on the graph model's parameters and statistics first)
+    resync()
+    for i in range(4):
+        on_both(train_step, i)
+    assert g.stats['recaptures'] == 1 and g.stats['captures'] == n_cap + 1
