@@ -62,3 +62,27 @@ for K, N in shapes:
         out = torch.zeros(N, K, device='cuda')
         t = timeit(lambda: ops.linear_wgrad(dy, x, out))
         print('wgrad          M=%d K=%4d N=%4d  %7.1f us  %7.1f TF/s' % (M, K, N, t * 1e6, fl / t / 1e12), flush=True)
+
+
+if os.environ.get('GB_DEFER_AB'):
+    if not hasattr(ops, 'GEMM_DEFER'):
+        raise SystemExit('the deferred-epilogue prototype is not in the product: git apply tools/gemm_defer_prototype.patch, rebuild, run again')
+    # same process, alternating: the plain launches as 256-row tiles, as 224-row tiles, and with the deferred epilogue
+    # (gemm256q.h DEFER, 224-row tiles)
+    print('--- deferred epilogue A/B (alternating, %d rounds of %d launches; lib %s) ---' % (5, reps, os.path.basename(_lib.LIB_PATH)))
+    for K, N in [(728, 1536), (2912, 728), (728, 728), (1536, 728), (728, 512), (512, 728), (728, 2912)]:
+        x, w = rnd(M, K), rnd(N, K)
+        fl = 2.0 * M * N * K
+        ts = {0: [], 1: [], 2: []}
+        ys = {}
+        for r in range(5):
+            for d in (0, 2, 1):
+                ops.GEMM_DEFER[0] = d
+                ts[d].append(timeit(lambda: ops.linear_fwd(x, w, pad=True)))
+                if r == 0:
+                    ys[d] = ops.linear_fwd(x, w, pad=True).clone()
+        ops.GEMM_DEFER[0] = 0
+        same = bool(torch.equal(ys[0], ys[1])) and bool(torch.equal(ys[0], ys[2]))
+        a, c, b = sorted(ts[0])[2], sorted(ts[2])[2], sorted(ts[1])[2]
+        print('plain K=%4d N=%4d  256-row %7.1f us (%6.1f TF/s)  224-row %7.1f us  deferred 224-row %7.1f us (%6.1f TF/s)  %+5.1f %% vs 256, %+5.1f %% vs 224  identical %s'
+              % (K, N, a * 1e6, fl / a / 1e12, c * 1e6, b * 1e6, fl / b / 1e12, (b / a - 1) * 100, (b / c - 1) * 100, same), flush=True)
