@@ -184,7 +184,8 @@ def refresh_stale_operands() -> int:
     shorter than the ~5 us a launch occupies the queue for).  Returns the number of weights re-cast."""
     import ctypes as C
     _refresh_derived()
-    if _static[0]:
+    static = static_addresses()
+    if static:
         _refresh_plain_copies()
     todo = []
     for key, (refs, out, wt) in list(_operands.items()):
@@ -205,7 +206,7 @@ def refresh_stale_operands() -> int:
             del out, wt, hit
             idle = (_idle_holder_counts(_operands[key][1]._base is not None)[:3]
                     + _idle_holder_counts(_operands[key][2]._base is not None)[3:])
-            if not _static[0] and any(a > b for a, b in zip(_operand_holders(key), idle)):
+            if not static and any(a > b for a, b in zip(_operand_holders(key), idle)):
                 _refs, out, _wt = _operands[key]
                 _operands.pop(key, None)
                 _wcache.pop(key, None)
@@ -261,7 +262,7 @@ def _refresh_derived() -> int:
         if w is None:
             _derived.pop(key, None)
         elif ver != _versions((w,)):
-            if _static[0]:
+            if static_addresses():
                 # captured HIP graphs hold the ADDRESS of the layout (parallel.StepGraphs): rebuilt in place
                 _out.copy_(builder(w))
                 _derived[key] = (ref, _versions((w,)), _out, builder)
@@ -279,12 +280,18 @@ def _refresh_derived() -> int:
 # parameter changes before backward): with graphs on, parameters must not be modified between a forward and its backward
 # -- which the graphs' own static activations forbid anyway.
 _static = [False]
+_static_holders = weakref.WeakSet()     # parallel.StepGraphs objects: the mode is on while any of them holds a captured graph
 
 
 def set_static_addresses(on: bool) -> bool:
+    """explicit switch (beside the automatic one: on while a parallel.StepGraphs holds captured graphs)"""
     prev = _static[0]
     _static[0] = bool(on)
     return prev
+
+
+def static_addresses() -> bool:
+    return _static[0] or any(h.entries for h in _static_holders)
 
 
 def _refresh_plain_copies() -> int:

@@ -456,9 +456,19 @@ class _ReplayBackward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        from . import functional as Fn
         entry, ctx.entry, ctx.token = ctx.entry, None, None
         entry.static_gout.copy_(g)
+        # A launch-by-launch backward pass may share this autograd pass (a second forward that fell back): its weight-gradient
+        # launches sit on the side stream and read-modify-write the same .grad buffers as the graph's.  Order them: what the
+        # side stream has so far, then the graph, then whatever it gets later.  (No-ops in the all-graph loop.)
+        cur = torch.cuda.current_stream(g.device)
+        side = Fn._overlap['streams'].get(g.device.index)
+        if side is not None:
+            cur.wait_stream(side)
         entry.g_bwd.replay()
+        if side is not None:
+            side.wait_stream(cur)
         return None, None, None
 
 
@@ -492,7 +502,9 @@ class StepGraphs:
 
     def __init__(self, model: torch.nn.Module, forward_eager, warmup: int = 2, max_entries: int = 4):
         self.model = weakref.ref(model)
-        self.forward_eager = forward_eager
+        # (a bound method of the model would make model -> StepGraphs -> model a cycle only the garbage collector breaks:
+        #  the graphs' memory pools, and static-address mode, would outlive the model for as long as that takes)
+        self._fwd = weakref.WeakMethod(forward_eager) if hasattr(forward_eager, '__self__') else (lambda f=forward_eager: f)
         self.warmup = int(warmup)
         self.max_entries = int(max_entries)
         self.entries = {}
@@ -502,6 +514,11 @@ class StepGraphs:
         self.live = None
         self.stats = {'captures': 0, 'replays': 0, 'eager': 0, 'recaptures': 0}
         self.last_reason = None
+        from . import ops
+        ops._static_holders.add(self)   # static-address mode is on exactly while some StepGraphs holds a captured graph
+
+    def forward_eager(self, x):
+        return self._fwd()(x)
 
     # -- preconditions -----------------------------------------------------------------------------------------------
     def _live(self):
@@ -591,7 +608,6 @@ class StepGraphs:
         from . import functional as Fn
         from . import ops
         from . import stem as stem_mod
-        ops.set_static_addresses(True)
         Fn.flush_stale_joins()
         if self.anchor is None or self.anchor.device != x.device:
             self.anchor = torch.zeros((), device=x.device, requires_grad=True)
@@ -600,9 +616,33 @@ class StepGraphs:
         ent.fingerprint = fp
         ent.static_x = x.detach().clone()
         ent.static_gout = ent.g_bwd = None
+        self.entries[key] = ent         # from here on ops.static_addresses() is true: every refresh is in place
         ops.refresh_stale_operands()
         ent.pool = torch.cuda.graph_pool_handle()
         ent.g_fwd = torch.cuda.CUDAGraph()
+        # The statistics arena of the launch-by-launch path (stem._arena: one buffer, zeroed once per forward, the backward's
+        # accumulators cut from it behind the forward's) must not be shared with a graph: a launch-by-launch forward between
+        # this entry's forward and backward would zero and re-cut what the captured backward accumulates into.  The capture
+        # starts from an empty arena: the captured forward then allocates one of its own from the graph's pool.
+        arena_saved = dict(stem_mod._arena)
+        stem_mod._arena.update(buf=None, off=0, need=max(arena_saved['need'], arena_saved['off']))
+        try:
+            self._capture_graphs(ent, grads)
+        except BaseException:
+            self.entries.pop(key, None)
+            raise
+        finally:
+            arena_private = stem_mod._arena.get('buf')
+            stem_mod._arena.clear()
+            stem_mod._arena.update(arena_saved)
+        # everything outside the graphs' pool whose ADDRESS they captured stays alive with them
+        ent.keep = ([h[2] for h in ops._wcache.values()] + [d[2] for d in ops._derived.values()]
+                    + [arena_private] + [v[1:] for v in ops._operands.values()])
+        self.entries[key] = ent
+        self.stats['captures'] += 1
+        return ent
+
+    def _capture_graphs(self, ent, grads):
         with torch.set_grad_enabled(grads):
             with torch.cuda.graph(ent.g_fwd, pool=ent.pool):
                 out = self.forward_eager(ent.static_x)
@@ -622,12 +662,6 @@ class StepGraphs:
                         if g is not None:
                             p.grad.add_(g)
                 del got
-        # everything outside the graphs' pool whose ADDRESS they captured stays alive with them
-        ent.keep = ([h[2] for h in ops._wcache.values()] + [d[2] for d in ops._derived.values()]
-                    + [stem_mod._arena.get('buf')] + [v[1:] for v in ops._operands.values()])
-        self.entries[key] = ent
-        self.stats['captures'] += 1
-        return ent
 
     def drop(self):
         """forget every captured graph (each entry's pool is released once the last reference is gone)"""

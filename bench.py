@@ -423,6 +423,32 @@ def other_configs(a, local_rank, steps=10, warmup=5):
                     'what': 'train-mode forward, no_grad' if forward_only else 'train step (fwd+bwd+fused SGD)',
                     'loss' if not forward_only else 'logit_sum': round(float(last.item()), 5),
                     'wall_s_incl_build': round(time.perf_counter() - t_build, 1)})
+        if fp8 and not forward_only:
+            # say in the line what C5 is.  The same steps with bf16 operands at the SAME batch, same box.
+            for m in model.modules():
+                if hasattr(m, 'attn_fp8'):
+                    m.attn_fp8 = False
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            dtb = (time.perf_counter() - t0) / steps
+            for m in model.modules():
+                if hasattr(m, 'attn_fp8'):
+                    m.attn_fp8 = True
+            rec['bf16_same_batch'] = {'ms_per_step': round(dtb * 1e3, 3), 'clips_per_s': round(batch / dtb, 2),
+                                      'fp8_over_bf16_time': round(dt / dtb, 4)}
+            rec['note'] = ('a NUMERICS configuration, not a performance one: the e4m3 operands are converted in registers and fed '
+                           'to the non-scaled v_mfma_f32_16x16x32_fp8_fp8, which runs at the bf16 rate on gfx950.  The 2x form '
+                           '(v_mfma_scale_f32_16x16x128_f8f6f4) contracts 128 deep per instruction: Q K^T contracts over d_head = 64, so '
+                           'half of every such instruction would multiply padding (= the bf16 rate again), only P V (contraction over '
+                           'keys) could use it, and both attention kernels are bound by softmax vector issue and q/k/v bytes '
+                           '(0.48 / 0.39 of min(MFMA, AI x HBM)), not by the MFMA pipe; spatial attention is 2.5 ms of a 52 ms step.  '
+                           'fp8 q/k/v written by the QKV GEMM would halve the attention READ bytes but the backward needs the '
+                           'bf16 values (or loses gradient accuracy): not built')
         if forward_only or batch * frames <= 32:
             # launch-bound legs: the same steps replayed as captured HIP graphs (parallel.StepGraphs)
             model.enable_step_graphs(True)

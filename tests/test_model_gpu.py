@@ -1156,6 +1156,13 @@ def test_step_graphs_give_the_bits_of_the_launch_by_launch_loop(dtype):
     assert torch.equal(outs[0][1], outs[1][1])
     for k, v in outs[0][2].items():                         # BatchNorm running statistics and batch counters too
         assert torch.equal(v, outs[1][2][k]), k
+    # static-address mode (cached operand copies refreshed in place) lasts exactly as long as captured graphs do
+    from istvt_amd import ops
+    assert ops.static_addresses()
+    made[1][0].enable_step_graphs(False)
+    import gc
+    gc.collect()
+    assert not ops.static_addresses()
 
 
 def test_step_graphs_fall_back_and_recapture():
@@ -1259,3 +1266,5 @@ def test_step_graphs_fall_back_and_recapture():
     for i in range(4):
         on_both(train_step, i)
     assert g.stats['recaptures'] == 1 and g.stats['captures'] == n_cap + 1
+    g.drop()
+    assert not ops.static_addresses()
