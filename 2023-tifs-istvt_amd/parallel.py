@@ -492,6 +492,8 @@ class StepGraphs:
         kernels write the bucket directly; a torch optimizer's ``zero_grad(set_to_none=True)`` breaks that and is detected);
       * no early all-reduce hook (N > 1 with the overlapped schedule stays launch-by-launch: the collective's handle is host state);
       * no per-kernel instrumentation (bench.py's profiled step);
+      * the switches that change the launch sequence (compute dtype, fp8 attention operands, dead-row elimination, the
+        weight-gradient stream / grouping) are part of an entry's key: a toggle captures a new entry, it never replays the old one;
       * the previous graphed forward of this entry has had its backward (or was dropped): an entry owns ONE set of saved
         activations.
     Addresses: parameters, gradients and every cached operand copy must stay where they were at capture; the cached copies are
@@ -512,6 +514,7 @@ class StepGraphs:
         self.pending = {}               # entry key -> weakref to the token of a graphed forward whose backward has not run
         self.anchor = None
         self.live = None
+        self._probe = None
         self.stats = {'captures': 0, 'replays': 0, 'eager': 0, 'recaptures': 0}
         self.last_reason = None
         from . import ops
@@ -519,6 +522,19 @@ class StepGraphs:
 
     def forward_eager(self, x):
         return self._fwd()(x)
+
+    def _config(self, m):
+        from . import functional as Fn
+        if m is None:
+            return None
+        if self._probe is None:
+            fp8 = [mod for mod in m.modules() if hasattr(mod, 'attn_fp8')]
+            dre = [mod for mod in m.modules() if hasattr(mod, 'dead_row_elimination')]
+            self._probe = (fp8, dre)
+        fp8, dre = self._probe
+        return (str(getattr(m, 'compute_dtype', None)), tuple(bool(q.attn_fp8) for q in fp8[:1]) + tuple(bool(q.attn_fp8) for q in fp8[-1:]),
+                tuple(bool(q.dead_row_elimination) for q in dre), bool(Fn._overlap['on']), int(Fn._overlap['group']),
+                os.environ.get('ISTVT_GEMM_TM', ''))
 
     # -- preconditions -----------------------------------------------------------------------------------------------
     def _live(self):
@@ -561,7 +577,9 @@ class StepGraphs:
         from . import ops
         m = self.model()
         grads = torch.is_grad_enabled()
-        key = (tuple(x.shape), x.dtype, x.device.index, bool(m is not None and m.training), grads)
+        # the key names everything that selects a launch sequence: the input, the mode, and the switches that change which
+        # kernels a forward / backward issues (a toggle after a capture must not replay the old sequence)
+        key = (tuple(x.shape), x.dtype, x.device.index, self._config(m), bool(m is not None and m.training), grads)
         reason = self.why_not(x, key)
         fp = None
         if reason is None:
@@ -644,13 +662,13 @@ class StepGraphs:
 
     def _capture_graphs(self, ent, grads):
         with torch.set_grad_enabled(grads):
-            with torch.cuda.graph(ent.g_fwd, pool=ent.pool):
+            with torch.cuda.graph(ent.g_fwd, pool=ent.pool, capture_error_mode='thread_local'):
                 out = self.forward_eager(ent.static_x)
             ent.static_out = out
             if grads:
                 ent.static_gout = torch.zeros_like(out)
                 ent.g_bwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ent.g_bwd, pool=ent.pool):
+                with torch.cuda.graph(ent.g_bwd, pool=ent.pool, capture_error_mode='thread_local'):
                     # autograd.grad, not backward(): no AccumulateGrad node runs (those of the warm-up steps live on the
                     # default stream, and the engine's stream hand-over to them is illegal inside a capture -- it crashed
                     # the process); the kernels write the fused bucket themselves and the Functions return None for their

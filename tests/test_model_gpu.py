@@ -1253,6 +1253,14 @@ def test_step_graphs_fall_back_and_recapture():
     assert g.stats['eager'] == n_eager + 1 and g.last_reason == 'a live gradient is not a fused-bucket view'
     for p, gr in zip(bucket.params, saved):
         p.grad = gr
+    # (4b) a switch that changes the launch sequence (dead-row elimination: identical results, fewer launches) is part of the
+    # key: the old entry is not replayed for the new configuration
+    n_ent = len(g.entries)
+    model.set_dead_row_elimination(True)
+    for i in range(3):
+        train_step(model, bucket, opt, i)
+    assert len(g.entries) == n_ent + 1
+    model.set_dead_row_elimination(False)
     # (5) a new bucket (gradients and parameters at new addresses): noticed, captured again, still the launch-by-launch bits
     n_cap = g.stats['captures']
     for m, b, o in made:
