@@ -229,8 +229,9 @@ class HostScalar:
     (right after the loss / the accuracy count, before ``backward()``) records an event there and copies device -> pinned
     host memory on a stream of its own behind that event; ``.item()`` -- called where the loop needs the number, after
     ``optimizer.step()`` -- waits for that copy only, which finished while the backward pass was still running.  Same
-    values at the same program points as the reference loop, no device-wide sync (tools/host_boundary_probe.py:
-    53.5 ms per step against 54.9 with ``.item()``, 53.1 with resident inputs and no readback)."""
+    values at the same program points as the reference loop, no device-wide sync (tools/host_boundary_probe.py, round 6 with
+    the probe's upload race fixed: 52.86 ms per step against 53.22 with ``.item()``, 52.33 with resident inputs and no
+    readback; round 5, before the host work at the head of a step moved behind the optimizer step: 53.5 / 54.9 / 53.1)."""
 
     _streams: dict = {}
 
