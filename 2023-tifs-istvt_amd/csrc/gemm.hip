@@ -44,6 +44,7 @@ struct GemmArgs {
     int a_sel_col;        // gemm256q: > 0: column tiles at or past this column take their A rows from a SECOND plane,
     int a2_off;           //   a2_off bytes behind A (istvt_gemm flags bit 1: the plane follows the first one, M rows of lda)
     void* dbg;            // diagnostic builds (-DISTVT_GEMM_DIAG): where the in-kernel stamps go when C2 is a real operand
+    int gelu_d;           // istvt_gemm flags bit 4: epi 1 stores gelu'(u) in C instead of u; epi 2 multiplies by the saved derivative in C2
 };
 
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -98,6 +99,17 @@ __device__ __forceinline__ gf2 gelu_fast2(gf2 u) {
     gf2 e;
     const gf2 ea = erf_abs2(gf2{fabsf(x.x), fabsf(x.y)}, e);
     const gf2 er = gf2{copysignf(ea.x, x.x), copysignf(ea.y, x.y)};
+    const gf2 hu = u * gf2{0.5f, 0.5f};
+    return hu * er + hu;
+}
+// gelu(u) and gelu'(u) from ONE erf / exp pair (the Gaussian of gelu' is the exponential of the erf approximation):
+// what the forward epilogue stores when the backward is to multiply by a saved derivative (istvt_gemm flags bit 4)
+__device__ __forceinline__ gf2 gelu_both_fast2(gf2 u, gf2& grad) {
+    const gf2 x = u * gf2{0.70710678118654752440f, 0.70710678118654752440f};
+    gf2 e;                                                                                   // exp(-u*u/2)
+    const gf2 ea = erf_abs2(gf2{fabsf(x.x), fabsf(x.y)}, e);
+    const gf2 er = gf2{copysignf(ea.x, x.x), copysignf(ea.y, x.y)};
+    grad = (u * gf2{0.39894228040143267794f, 0.39894228040143267794f}) * e + (er * gf2{0.5f, 0.5f} + gf2{0.5f, 0.5f});
     const gf2 hu = u * gf2{0.5f, 0.5f};
     return hu * er + hu;
 }
@@ -327,6 +339,8 @@ extern "C" int istvt_gemm(const void* A, long lda, int a_kc, const void* B, long
     a.slab = out_mode == 3 ? (long)M * ldc : 0;
     a.st_sum = col_sum; a.st_sumsq = col_sumsq;
     a.blocked = flags & 1;
+    a.gelu_d = (flags >> 4) & 1;
+    if (a.gelu_d && epi == EPI_NONE) return ISTVT_ERR_SHAPE;
     const bool a_sel = (flags & 2) != 0;
     const int cu_reserve = ((flags >> 8) & 0xff) * 8;
     if (cu_reserve > 192) return ISTVT_ERR_SHAPE;

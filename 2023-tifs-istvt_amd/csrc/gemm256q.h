@@ -350,6 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 
     float* slab = reinterpret_cast<float*>(smem + QNU * QU_BYTES + wave * PSLAB_BYTES);
     const float alpha = p.alpha;
+    const bool gelu_d = p.gelu_d != 0;          // uniform: the GELU epilogues exchange gelu'(u) instead of u (flags bit 4)
     const int colc = (lane & 7) * 8;
     const int erow = lane >> 3;
     const char* side = EPI == EPI_GELU_BWD ? (const char*)p.C2 : (const char*)p.residual;
@@ -831,6 +832,7 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
                         if constexpr ((DBG & 2048) != 0) { v[j] *= (float)u[j]; v[j + 1] *= (float)u[j + 1]; continue; }   // no GELU arithmetic
+                        if (gelu_d) { v[j] *= (float)u[j]; v[j + 1] *= (float)u[j + 1]; continue; }      // C2 holds gelu'(u), saved by the forward
                         const gf2 gg = gelu_grad_fast2(gf2{(float)u[j], (float)u[j + 1]});
                         v[j] *= gg.x; v[j + 1] *= gg.y;
                     }
@@ -839,9 +841,20 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += (float)u[j];
                 }
-                bf16x8 o;
+                bf16x8 o, o2e;
+                if (EPI == EPI_GELU_FWD && gelu_d) {
+                    // the forward keeps gelu'(u) instead of u (all the backward needs of it): one erf / exp pair gives both
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        gf2 gg;
+                        const gf2 gv = gelu_both_fast2(gf2{v[j], v[j + 1]}, gg);
+                        o[j] = (bf16_t)gg.x; o[j + 1] = (bf16_t)gg.y;
+                        o2e[j] = (bf16_t)gv.x; o2e[j + 1] = (bf16_t)gv.y;
+                    }
+                } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+                }
                 if constexpr (STATS != 0) {
                     if (voff != OOB) {                  // a row and a column chunk inside the matrix
 #pragma unroll
@@ -856,6 +869,8 @@ __global__ __launch_bounds__(512, 2) void gemm256q_kernel(GemmArgs p) {
                 __builtin_amdgcn_raw_buffer_store_b128(held[it], c_rs, voff, soff, ISTVT_Q_STORE_AUX);
                 if (EPI == EPI_GELU_FWD) {
                     bf16x8 o2;
+                    if (gelu_d) o2 = o2e;
+                    else
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
                         if constexpr ((DBG & 2048) != 0) { o2[j] = (bf16_t)(v[j] + 1.0f); o2[j + 1] = (bf16_t)(v[j + 1] + 1.0f); continue; }

@@ -30,6 +30,10 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& p, int m, int n, 
         for (int j = 0; j < 4; ++j) gv[j] = gelu_f(v[j]);
         T* c = (T*)p.C + off;
         T* c2 = (T*)p.C2 + off;
+        if (p.gelu_d) {                 // C takes gelu'(u): all the backward needs of u
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_grad_f(v[j]);
+        }
         if (nvec) { store4(c, v); store4(c2, gv); }
         else { for (int j = 0; j < nv; ++j) { c[j] = from_f32<T>(v[j]); c2[j] = from_f32<T>(gv[j]); } }
         return;
@@ -39,7 +43,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& p, int m, int n, 
         float uv[4] = {0.f, 0.f, 0.f, 0.f};
         if (nvec) load4(u, uv); else { for (int j = 0; j < nv; ++j) uv[j] = to_f32(u[j]); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(uv[j]);
+        for (int j = 0; j < 4; ++j) v[j] *= p.gelu_d ? uv[j] : gelu_grad_f(uv[j]);
     }
     if (p.residual) {
         const T* rp = (const T*)p.residual + (long)m * p.ldr + n;

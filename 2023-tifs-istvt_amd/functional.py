@@ -439,12 +439,20 @@ class LinearCatSelFn(Function):
         return (dx, None, None, *grads)
 
 
+# The GELU pair exchanges gelu'(u) instead of u (round 6): the forward GEMM's epilogue has the fp32 pre-activation and the
+# erf / exp of gelu in registers, so gelu'(u) costs it two more FMAs per element; the backward GEMM's epilogue then multiplies
+# by the saved value instead of evaluating erf and exp again (27 % of that epilogue, profiles/r05_a_*).  u itself is used by
+# nothing else.  float32: bit-identical (the same gelu'(fp32 u), computed one kernel earlier).  ISTVT_GELU_SAVE_DERIV=0: the u form.
+GELU_SAVE_DERIV = [os.environ.get('ISTVT_GELU_SAVE_DERIV', '1') != '0']
+
+
 class FeedForwardFn(Function):
     """Linear -> exact GELU -> Linear (+ residual) (FeedForward, module.py:23-34)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual, defer_bias=False):
-        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True)
+        ctx.gelu_d = GELU_SAVE_DERIV[0]
+        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True, gelu_d=ctx.gelu_d)
         y = ops.linear_fwd(g, ops.weight_as(w2, x.dtype, pad=True), b2, residual, pad=True)
         ctx.save_for_backward(x, u, g, w1, b1, w2, b2)
         ctx.has_res = residual is not None
@@ -457,7 +465,7 @@ class FeedForwardFn(Function):
         x, u, g, w1, b1, w2, b2 = ctx.saved_tensors
         # (dy W2) * gelu'(u); the hidden layer's bias gradient = its column sums, taken in that GEMM's epilogue
         buf1, db1 = _target(b1)
-        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True, csum=buf1)
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True, csum=buf1, gelu_d=ctx.gelu_d)
         dw2 = _wgrad(dy, g, w2)
         db2 = None if ctx.defer_bias else _bgrad(dy, b2)
         dx = ops.linear_dgrad(du, ops.weight_as(w1, dy.dtype, pad=True), pad=True) if ctx.needs_input_grad[0] else None
@@ -637,7 +645,8 @@ class FeedForwardDropFn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, p1, p2, seed1, seed2):
-        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True)
+        ctx.gelu_d = GELU_SAVE_DERIV[0]
+        u, g = ops.linear_fwd(x, ops.weight_as(w1, x.dtype, pad=True), b1, gelu=True, pad=True, gelu_d=ctx.gelu_d)
         m1 = m2 = None
         if p1 > 0:
             g, m1 = _dropout_fwd(g, p1, seed1)
@@ -655,7 +664,7 @@ class FeedForwardDropFn(Function):
         p1, p2 = ctx.p
         if m2 is not None:
             dy = _dropout_bwd(dy, m2, p2)
-        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True)
+        du = ops.linear_dgrad(dy, ops.weight_as(w2, dy.dtype, pad=True), gelu_u=u, pad=True, gelu_d=ctx.gelu_d)
         if m1 is not None:
             du = _dropout_bwd(du, m1, p1)
         dw2 = _wgrad(dy, g, w2)

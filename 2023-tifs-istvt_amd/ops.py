@@ -493,7 +493,8 @@ def gemm_kernel_name(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, epi=0, residua
 def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C: Tensor, ldc: int, M: int, N: int,
              K: int, *, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, ldr: int = 0,
              C2: Optional[Tensor] = None, epi: int = 0, out_mode: int = 0, splitk: int = 1, alpha: float = 1.0,
-             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None, blocked: bool = True, a_sel_col: int = 0):
+             stats: Optional[Tensor] = None, csum: Optional[Tensor] = None, blocked: bool = True, a_sel_col: int = 0,
+             gelu_d: bool = False):
     """stats: double [R][2][N] accumulator (stem.new_stats): the kernel adds the column sums / sums of squares of the
     stored outputs (fused train-mode BatchNorm statistics); only legal where stats_fusable() says so.
     csum=True (with stats, epi 2 only): only the column sums are accumulated (a bias gradient; the caller folds them
@@ -516,7 +517,7 @@ def gemm_raw(A: Tensor, lda: int, a_kc: bool, B: Tensor, ldb: int, b_kc: bool, C
                                _ptr(bias), _ptr(residual), ldr, _ptr(C2), epi, out_mode, splitk, alpha,
                                stats[0, 0].data_ptr() if stats is not None else None,
                                stats[0, 1].data_ptr() if (stats is not None and csum is None) else None,
-                               int(bool(blocked)) | ((2 | ((a_sel_col // 64) << 16)) if a_sel_col else 0)
+                               int(bool(blocked)) | ((2 | ((a_sel_col // 64) << 16)) if a_sel_col else 0) | (16 if gelu_d else 0)
                                | ((_cu_reserve.get(A.device.index, 0) >> 3) << 8 if _cu_reserve else 0),
                                dtype_code(A), _stream())
     if prof is not None:
@@ -565,8 +566,9 @@ def stats_fusable(x: Tensor, w: Tensor) -> bool:
 
 def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
                gelu: bool = False, pad: bool = False, stats: Optional[Tensor] = None, blocked: bool = True,
-               a_sel_col: int = 0):
-    """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)).  x [M,K], w [N,K] (x's dtype); both may
+               a_sel_col: int = 0, gelu_d: bool = False):
+    """y = x @ w.T (+bias) (+residual); with gelu=True returns (u, gelu(u)) -- (gelu'(u), gelu(u)) with gelu_d=True: the
+    derivative is all FeedForward's backward needs of u (istvt_gemm flags bit 4; pass the same flag to linear_dgrad).  x [M,K], w [N,K] (x's dtype); both may
     be row-strided views.  pad=True: the outputs are [M, N] views with line-aligned rows.  stats: see gemm_raw."""
     M, K = x.shape
     N = w.shape[0]
@@ -578,7 +580,7 @@ def linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Op
     ldc = y.stride(0) if M > 1 else N
     if gelu:
         g = empty_rows(M, N, x.dtype, x.device, pad)
-        gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, C2=g, epi=1, blocked=blocked)
+        gemm_raw(x, lda, True, w, ldb, True, y, ldc, M, N, K, bias=bias, C2=g, epi=1, blocked=blocked, gelu_d=gelu_d)
         return y, g
     ldr = 0
     if residual is not None:
@@ -618,8 +620,9 @@ def _transposed_operand(w: Tensor) -> Tensor:
 
 
 def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Optional[Tensor] = None,
-                 pad: bool = False, csum: Optional[Tensor] = None, blocked: bool = True) -> Tensor:
-    """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u).
+                 pad: bool = False, csum: Optional[Tensor] = None, blocked: bool = True, gelu_d: bool = False) -> Tensor:
+    """dx = dy @ w  (dy [M,N], w [N,K]); with gelu_u: dx *= gelu'(gelu_u) (dx shaped like gelu_u); gelu_d=True: gelu_u IS the
+    derivative linear_fwd(gelu=True, gelu_d=True) saved, dx *= gelu_u.
     wt = w^T [K,N] (optional): use the k-contiguous kernel instead of the transposed-operand one.
     csum (with gelu_u): float32 [K] += column sums of dx, taken in the GEMM's epilogue where the kernel supports it
     (else by a colsum pass here): the bias gradient of the Linear whose pre-activation gelu_u is."""
@@ -646,15 +649,15 @@ def linear_dgrad(dy: Tensor, w: Tensor, gelu_u: Optional[Tensor] = None, wt: Opt
             # addresses of the gradient itself serialise on same-address atomics (+60 us per launch, measured)
             from . import stem as _stem
             acc = _stem.new_stats(K, dy.device)
-            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, stats=acc, csum=True)
+            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, stats=acc, csum=True, gelu_d=gelu_d)
             _lib.check(_lib.lib().istvt_stats_reduce_add(acc.data_ptr(), K, csum.data_ptr(), _stream()), 'istvt_stats_reduce_add')
         else:
-            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, blocked=blocked)
+            gemm_raw(dy, lda, True, wt, ldb, True, dx, ldc, M, K, N, C2=c2, epi=epi, blocked=blocked, gelu_d=gelu_d)
             if csum is not None:
                 colsum(dx, out=csum)
     else:
         w, ldb = rows(w)
-        gemm_raw(dy, lda, True, w, ldb, False, dx, ldc, M, K, N, C2=c2, epi=epi, blocked=blocked)
+        gemm_raw(dy, lda, True, w, ldb, False, dx, ldc, M, K, N, C2=c2, epi=epi, blocked=blocked, gelu_d=gelu_d)
         if csum is not None:
             colsum(dx, out=csum)
     return dx

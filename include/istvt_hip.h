@@ -67,6 +67,11 @@ typedef void* istvt_stream_t; /* hipStream_t */
  *           second directly behind the first (A + M * lda elements); output columns at or past 64 * (flags >> 16), a
  *           multiple of 256, take their rows from the second plane.  TemporalResidualAttention (module.py:193-196): q | k
  *           are projections of the frame-differenced LayerNorm output, v of the plain one -- one 728 -> 1536 GEMM.
+ *           bit 4 (with epi 1 or 2, -3 otherwise): the GELU pair exchanges the DERIVATIVE instead of the pre-activation.
+ *           epi 1 then stores C = gelu'(u) (computed from the fp32 u with the erf / exp of gelu itself), C2 = gelu(u); epi 2
+ *           computes C = acc * C2 with C2 = that saved derivative.  FeedForward's backward (module.py:27-30) needs u for
+ *           nothing else, so the same bytes carry what the backward would recompute per element; in float32 the result is
+ *           bit-identical to the u form.
  *           bits 8..15: CUs, in units of 8 (at most 24 = 192 CUs, -3 otherwise), that a launch of the persistent NT kernel
  *           leaves free: set while a collective's kernels occupy CUs (the data-parallel gradient all-reduce that overlaps
  *           the stem backward, train_CNN.py:185-186 -> parallel.GradBucket), so that every persistent workgroup is resident

@@ -109,6 +109,17 @@ def gemm_real(dtype, mode):
         ru = x.double() @ w.double().t() + b.double()
         rg = torch.nn.functional.gelu(ru)
         return max(relerr(u, ru), relerr(g, rg)), TOL[dtype]
+    elif mode == 'fwd_gelu_d':      # istvt_gemm flags bit 4: C = gelu'(u), C2 = gelu(u)
+        x, w, b = rnd((M, 728), dtype, 1), rnd((2912, 728), dtype, 2, 728 ** -0.5), rnd((2912,), torch.float32, 3)
+        d, g = ops.linear_fwd(x, w, b, gelu=True, gelu_d=True)
+        ru = (x.double() @ w.double().t() + b.double()).requires_grad_(True)
+        rg = torch.nn.functional.gelu(ru)
+        rg.sum().backward()
+        return max(relerr(d, ru.grad), relerr(g, rg.detach())), TOL[dtype]
+    elif mode == 'dgrad_gelu_d':    # ... and C = acc * C2 with the saved derivative
+        dy, w, d = rnd((M, 728), dtype, 1), rnd((728, 2912), dtype, 2, 728 ** -0.5), rnd((M, 2912), dtype, 3)
+        y = ops.linear_dgrad(dy, w, gelu_u=d, gelu_d=True)
+        ref = (dy.double() @ w.double()) * d.double()
     elif mode == 'dgrad_gelu':
         dy, w, u = rnd((M, 728), dtype, 1), rnd((728, 2912), dtype, 2, 728 ** -0.5), rnd((M, 2912), dtype, 3)
         y = ops.linear_dgrad(dy, w, gelu_u=u)
@@ -409,7 +420,7 @@ def all_checks():
             out.append(('gemm_exact_big_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 515, 728, 1544)))
             out.append(('gemm_exact_k64_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 1030, 128, 64)))
             out.append(('gemm_exact_k40_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_exact(dt, mode, 700, 72, 40)))
-        for mode in ('fwd_bias_res', 'fwd_gelu', 'dgrad_gelu', 'wgrad', 'head'):
+        for mode in ('fwd_bias_res', 'fwd_gelu', 'dgrad_gelu', 'fwd_gelu_d', 'dgrad_gelu_d', 'wgrad', 'head'):
             out.append(('gemm_%s_%s' % (mode, tag), lambda dt=dt, mode=mode: gemm_real(dt, mode)))
         out.append(('gemm_padded_rows_%s' % tag, lambda dt=dt: gemm_padded(dt)))
         out.append(('layernorm_padded_rows_%s' % tag, lambda dt=dt: layernorm(dt, pad=True)))
@@ -914,10 +925,19 @@ def gemm_production(mode, N, K, M=M_C2, nsample=2048):
     idx = _sample_rows(M, nsample, seed=N + K)
     ic = idx.cuda()
     cpu = lambda t: t.detach().double().cpu()  # noqa: E731
-    if mode in ('fwd', 'fwd_bias_res', 'fwd_gelu'):
+    if mode in ('fwd', 'fwd_bias_res', 'fwd_gelu', 'fwd_gelu_d'):
         x, w = padded(ints((M, K), dt, 1)), padded(ints((N, K), dt, 2))
         b = ints((N,), torch.float32, 4) if mode != 'fwd' else None
         ref = cpu(x[ic]) @ cpu(w).t()
+        if mode == 'fwd_gelu_d':
+            d_, g_ = ops.linear_fwd(x, w, b, gelu=True, pad=True, gelu_d=True)
+            ru = (ref + cpu(b)).requires_grad_(True)           # the exact fp32 pre-activation (integer operands)
+            rg = torch.nn.functional.gelu(ru)
+            rg.sum().backward()
+            ed = float((cpu(d_[ic]) - ru.grad).abs().max())                           # gelu'(u) in [-0.13, 1.13]: absolute
+            eg = float((cpu(g_[ic]) - rg.detach()).abs().max() / rg.detach().abs().max())
+            assert d_.stride(0) == ops.pad_ld(N)
+            return max(0.0 if ed < 6e-3 else ed, 0.0 if eg < 1e-2 else eg), 0.0
         if mode == 'fwd_gelu':
             u, g_ = ops.linear_fwd(x, w, b, gelu=True, pad=True)
             ref = ref + cpu(b)
@@ -931,6 +951,13 @@ def gemm_production(mode, N, K, M=M_C2, nsample=2048):
         if mode == 'fwd_bias_res':
             ref = ref + cpu(b) + cpu(r[ic])
         return float((cpu(y[ic]) - ref.to(dt).double()).abs().max()), 0.0
+    if mode == 'dgrad_gelu_d':
+        dy, w = padded(ints((M, N), dt, 5, -1, 2)), ints((N, K), dt, 6)
+        d_ = ops.empty_rows(M, K, dt, DEV)
+        d_.copy_(rnd((M, K), dt, 7))
+        dx = ops.linear_dgrad(dy, w, gelu_u=d_, pad=True, gelu_d=True)
+        ref = (cpu(dy[ic]) @ cpu(w)) * cpu(d_[ic])
+        return relerr(cpu(dx[ic]), ref), TOL[dt]
     if mode in ('dgrad', 'dgrad_gelu'):
         # dx [M, K] = dy [M, N] @ w [N, K]  (runs as an NT GEMM over the cached, row-padded W^T)
         dy, w = padded(ints((M, N), dt, 5, -1, 2)), ints((N, K), dt, 6)
@@ -1042,6 +1069,9 @@ def all_checks():  # noqa: F811
     out.append(('gemm_khalf_edge_gelu_K96', lambda: gemm_production('fwd_gelu', 512, 96, M=3000, nsample=3000)))
     out.append(('gemm_khalf_edge_dgrad_gelu_K96', lambda: gemm_production('dgrad_gelu', 96, 512, M=3000, nsample=3000)))
     out.append(('gemm_production_dgrad_gelu_N728_K2912', lambda: gemm_production('dgrad_gelu', 728, 2912)))
+    out.append(('gemm_production_fwd_gelu_d_N2912_K728', lambda: gemm_production('fwd_gelu_d', 2912, 728)))
+    out.append(('gemm_production_dgrad_gelu_d_N728_K2912', lambda: gemm_production('dgrad_gelu_d', 728, 2912)))
+    out.append(('gemm_khalf_edge_gelu_d_K96', lambda: gemm_production('fwd_gelu_d', 512, 96, M=3000, nsample=3000)))
     out.append(('attn_spatial_production_BF2304', attn_spatial_production))
     out.append(('attn_spatial_production_P362', lambda: attn_spatial_production(448, 362, 8, 64, 16)))
     out.append(('attn_temporal_production_C2', attn_temporal_production))

@@ -337,3 +337,36 @@ def test_operand_refresh_spares_operands_held_by_a_live_graph():
     import gc
     gc.collect()
     assert key not in ops._operands and len(ops._operands) == n0 - 1            # the parameter died: copies released
+
+
+
+def test_gelu_saved_derivative_is_bit_identical_in_float32_and_close_in_bfloat16():
+    """FeedForward (module.py:23-34) with the GELU pair exchanging gelu'(u) instead of u (istvt_gemm flags bit 4, the default)
+    against the u form: float32 gives the same bits (the same gelu'(fp32 u), computed one kernel earlier); bfloat16 differs
+    by the rounding of the derivative (computed from the fp32 pre-activation now, from its bf16 rounding before)."""
+    import istvt_pkg
+    istvt_pkg.load()
+    from istvt_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 8e-3)):
+        res = []
+        for on in (True, False):
+            Fn.GELU_SAVE_DERIV[0] = on
+            try:
+                x = (torch.randn((700, 728), generator=torch.Generator().manual_seed(3)) * 0.7).cuda().to(dt).requires_grad_(True)
+                w1 = (torch.randn((2912, 728), generator=torch.Generator().manual_seed(4)) * 728 ** -0.5).cuda().requires_grad_(True)
+                b1 = torch.randn((2912,), generator=torch.Generator().manual_seed(5)).cuda().requires_grad_(True)
+                w2 = (torch.randn((728, 2912), generator=torch.Generator().manual_seed(6)) * 2912 ** -0.5).cuda().requires_grad_(True)
+                b2 = torch.randn((728,), generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
+                y = Fn.FeedForwardFn.apply(x, w1, b1, w2, b2, None)
+                dy = torch.randn((700, 728), generator=torch.Generator().manual_seed(8)).cuda().to(dt)
+                y.backward(dy)
+                torch.cuda.synchronize()
+                res.append([t.detach().float().clone() for t in (y, x.grad, w1.grad, b1.grad, w2.grad, b2.grad)])
+            finally:
+                Fn.GELU_SAVE_DERIV[0] = True
+        for a, b in zip(*res):
+            if tol == 0.0:
+                assert torch.equal(a, b)
+            else:
+                assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < tol
