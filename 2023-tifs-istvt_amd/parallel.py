@@ -535,7 +535,7 @@ class StepGraphs:
         fp8, dre = self._probe
         return (str(getattr(m, 'compute_dtype', None)), tuple(bool(q.attn_fp8) for q in fp8[:1]) + tuple(bool(q.attn_fp8) for q in fp8[-1:]),
                 tuple(bool(q.dead_row_elimination) for q in dre), bool(Fn._overlap['on']), int(Fn._overlap['group']),
-                os.environ.get('ISTVT_GEMM_TM', ''))
+                bool(Fn.GELU_SAVE_DERIV[0]), os.environ.get('ISTVT_GEMM_TM', ''))
 
     # -- preconditions -----------------------------------------------------------------------------------------------
     def _live(self):
