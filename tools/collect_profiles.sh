@@ -9,11 +9,11 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_single -- python3 bench.py --no-cpu-baseline --no-dre-extra --no-other-configs --no-host-boundary --no-wgrad-overlap > $out/bench_prof_single.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_overlap -- python3 bench.py --no-cpu-baseline --no-dre-extra --no-other-configs --no-host-boundary > $out/bench_prof_overlap.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_single -- python3 bench.py --no-cpu-baseline --no-dre-extra --no-other-configs --no-host-boundary --no-step-graphs --no-wgrad-overlap > $out/bench_prof_single.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_overlap -- python3 bench.py --no-cpu-baseline --no-dre-extra --no-other-configs --no-host-boundary --no-step-graphs > $out/bench_prof_overlap.log 2>&1
 cp $(ls $out/trace_single/*/*_kernel_stats.csv | head -1) $out/kernel_stats.csv
 cp $(ls $out/trace_overlap/*/*_kernel_stats.csv | head -1) $out/overlap_kernel_stats.csv
-B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-dre-extra --no-other-configs --no-wgrad-overlap --no-host-boundary"
+B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-dre-extra --no-other-configs --no-wgrad-overlap --no-host-boundary --no-step-graphs"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $B > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $B > $out/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_mfma -- $B > $out/pmc_mfma.log 2>&1
