@@ -577,3 +577,54 @@ def test_operand_refresh_baseline_is_mode_independent(pkg):
     ops._idle_counts.clear()
     b = (ops._idle_holder_counts(True), ops._idle_holder_counts(False))
     assert a == b
+
+
+def test_static_address_refresh_rewrites_cached_copies_in_place(pkg):
+    """parallel.StepGraphs relies on ops' static-address mode: every cached copy derived from a parameter is refreshed INTO
+    the buffer it lives in (captured HIP graphs hold its address).  The host logic, on CPU tensors: a plain cast, a weight_t_as
+    transpose, a stacked operand, the lazily made transpose of a cast copy and a derived layout -- all rewritten in place
+    after the parameters change; with the mode off, derived layouts are re-made (a live autograd graph keeps the old one)."""
+    import weakref
+    from istvt_amd import ops
+    saved = (dict(ops._wcache), dict(ops._operands), dict(ops._derived))
+    ops._wcache.clear(); ops._operands.clear(); ops._derived.clear()
+    try:
+        w = torch.nn.Parameter(torch.arange(12, dtype=torch.float32).reshape(3, 4))
+        v = torch.nn.Parameter(torch.ones(2, 4))
+        plain = w.detach().to(torch.bfloat16).clone()
+        plain_t = plain.t().contiguous().clone()
+        wt = w.detach().t().to(torch.bfloat16).contiguous().clone()
+        cat = torch.cat((w.detach(), v.detach())).to(torch.bfloat16).clone()
+        ver = ops._versions((w,))
+        ops._wcache[id(w)] = (weakref.ref(w), ver, plain)
+        ops._wcache[(id(plain), 'T')] = (weakref.ref(plain), 0, plain_t)
+        ops._wcache[(id(w), 't')] = (weakref.ref(w), ver, wt)
+        ops._wcache[((id(w), id(v)), 'cat')] = ((weakref.ref(w), weakref.ref(v)), ops._versions((w, v)), cat)
+        der = ops.derived((id(w), 'tap'), w, lambda q: q.detach().t().contiguous())
+        ptrs = [t.data_ptr() for t in (plain, plain_t, wt, cat, der)]
+        with torch.no_grad():
+            w.mul_(2.0)
+            v.add_(1.0)
+        # mode off: the derived layout is re-made at a new address, the plain copies are left to their lazy paths
+        assert not ops.static_addresses()
+        assert ops._refresh_derived() == 1 and ops._derived[(id(w), 'tap')][2].data_ptr() != ptrs[4]
+        with torch.no_grad():
+            w.add_(1.0)
+        prev = ops.set_static_addresses(True)
+        try:
+            der2 = ops._derived[(id(w), 'tap')][2]
+            p_der2 = der2.data_ptr()
+            assert ops._refresh_derived() == 1 and ops._derived[(id(w), 'tap')][2].data_ptr() == p_der2
+            assert torch.equal(der2, w.detach().t())
+            assert ops._refresh_plain_copies() == 3
+        finally:
+            ops.set_static_addresses(prev)
+        assert [t.data_ptr() for t in (plain, plain_t, wt, cat)] == ptrs[:4]
+        assert torch.equal(plain, w.detach().to(torch.bfloat16)) and torch.equal(plain_t, plain.t())
+        assert torch.equal(wt, w.detach().t().to(torch.bfloat16))
+        assert torch.equal(cat, torch.cat((w.detach(), v.detach())).to(torch.bfloat16))
+        assert ops._refresh_plain_copies() == 0                     # nothing stale any more
+    finally:
+        ops._wcache.clear(); ops._wcache.update(saved[0])
+        ops._operands.clear(); ops._operands.update(saved[1])
+        ops._derived.clear(); ops._derived.update(saved[2])
