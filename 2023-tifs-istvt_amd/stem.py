@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -303,10 +305,14 @@ class StemFn(Function):
             u2 = ops.linear_fwd(col2, w2, blocked=False)
             del col2
         bn2 = bn('bn2', u2, M2, 64)
-        a2 = bn_apply(u2, bn2, M2, 64, True)
+        # relu(bn2(u2)), block1's input (xception.py:121-125), is NOT materialised (round 6: a 0.8 GB read + write pass at C2):
+        # block1's first depthwise convolution applies bn2 + ReLU as it stages its input tile -- rounded to the storage type
+        # there, exactly where the separate pass rounded it --, its weight gradient takes the same pair on load, and the
+        # stride-2 skip path applies them to the quarter of the pixels it keeps.
         sv.update(x=x, S=S, Fr=Fr, H1=H1, H2=H2, u1=u1, bn1=bn1, u2=u2, bn2=bn2, w1=w1, w2=w2)
 
-        X, H = a2, H2
+        fuse_in = os.environ.get('ISTVT_STEM_MATERIALISE_A2', '0') != '1'     # (1: the separate bn_apply pass, for A/B runs)
+        X, H = (u2 if fuse_in else bn_apply(u2, bn2, M2, 64, True)), H2
         blocks = []
         for name, cin_, cout, pre_relu in BLOCKS:
             i0 = 1 if pre_relu else 0
@@ -318,13 +324,16 @@ class StemFn(Function):
             wdwB = tap_major(P['%s.rep.%d.conv1.weight' % (name, i0 + 3)])
             wpwB = ops.weight_as(P['%s.rep.%d.pointwise.weight' % (name, i0 + 3)], dtype, pad=True)
             wsk = ops.weight_as(P[name + '.skip.weight'], dtype, pad=True)
-            d1 = dwconv(X, wdwA, Fr, H, H, cin_, in_relu=pre_relu)
+            first = name == 'block1' and fuse_in          # its input X is u2: bn2 + ReLU ride on every load of it
+            d1 = dwconv(X, wdwA, Fr, H, H, cin_, in_bn=bn2 if first else None, in_relu=pre_relu or first)
             uA, bnA = pw_bn('%s.rep.%d' % (name, i0 + 1), d1, wpwA, M, cout)
             d2 = dwconv(uA, wdwB, Fr, H, H, cout, in_bn=bnA, in_relu=True)
             uB, bnB = pw_bn('%s.rep.%d' % (name, i0 + 4), d2, wpwB, M, cout)
             xs = torch.empty((Ms, cin_), dtype=dtype, device=dev)
             _lib.check(L.istvt_subsample2(X.data_ptr(), xs.data_ptr(), Fr, H, H, cin_, ops._DT[dtype], _stream()),
                        'istvt_subsample2')
+            if first:
+                xs = bn_apply(xs, bn2, Ms, cin_, True)
             uS, bnS = pw_bn(name + '.skipbn', xs, wsk, Ms, cout)
             out = torch.empty((Ms, cout), dtype=dtype, device=dev)
             amax = torch.empty((Ms, cout), dtype=torch.uint8, device=dev)
@@ -422,7 +431,9 @@ class StemFn(Function):
             lin_wgrad(sA + '.pointwise.weight', duA, blk['d1'])
             dd1 = ops.linear_dgrad(duA, blk['wpwA'], blocked=False)
             del duA
-            dw_wgrad(sA + '.conv1.weight', blk['X'], dd1, H, cin, None, blk['pre_relu'])
+            # (block1: X is u2 -- the convolution's input was relu(bn2(u2)), taken on load as in the forward)
+            fused_in = not blk['pre_relu'] and blk['X'] is sv['u2']
+            dw_wgrad(sA + '.conv1.weight', blk['X'], dd1, H, cin, sv['bn2'] if fused_in else None, True if fused_in else blk['pre_relu'])
             if blk['pre_relu']:
                 # d(block input) = relu'(X) * d(rep path) + scatter(d skip path)
                 dOut = dwconv(dd1, blk['wdwA'], Fr, H, H, cin, flip=True, msrc=blk['X'], mask_pre=True, addsrc=dxs)
