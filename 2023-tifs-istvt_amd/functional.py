@@ -334,6 +334,21 @@ def _wgrad(dy, x, weight):
     return None
 
 
+def side_launch(device, fn, keep=()):
+    """Run `fn` (launches whose results nothing later in this backward pass reads: weight gradients that land straight in
+    .grad) on the weight-gradient side stream, joined at the end of the backward pass like _wgrad's; `keep`: the operand
+    tensors, alive until the join.  Outside a backward pass, or with the overlap off, `fn` runs in place."""
+    if not (_overlap['on'] and device.type == 'cuda' and _graph_task() != -1):
+        fn()
+        return
+    dev, main = _ensure_join(device)
+    side = _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    _overlap['keep'].setdefault(dev, []).append(keep)
+
+
 def _bgrad(dy, bias):
     if bias is None:
         return None

@@ -381,15 +381,28 @@ class StemFn(Function):
                 grads[n + '.bias'] = db
             return du
 
+        # Weight gradients that land straight in .grad are read by nothing later in this pass: like the transformer's
+        # (functional._wgrad) they go to the side stream, beside the chain of memory-bound kernels of the stem backward
+        # (ISTVT_STEM_WGRAD_SIDE=0: in place, for A/B runs).
+        side_on = os.environ.get('ISTVT_STEM_WGRAD_SIDE', '1') != '0'
+
         def lin_wgrad(n, dyv, xv):
             q = P[n]
             t = tgt(n, (q.shape[0], -1))
+            if t is not None and side_on:
+                from . import functional as Fn
+                Fn.side_launch(dyv.device, lambda: ops.linear_wgrad(dyv, xv, out=t), keep=(dyv, xv))
+                return
             r = ops.linear_wgrad(dyv, xv, out=t)
             if t is None:
                 grads[n] = r
 
         def dw_wgrad(n, xv, dv, H_, C_, bn_, relu_):
             t = tgt(n, (C_, 9))
+            if t is not None and side_on:
+                from . import functional as Fn
+                Fn.side_launch(dv.device, lambda: dwconv_wgrad(xv, dv, Fr, H_, H_, C_, bn_, relu_, out=t), keep=(xv, dv, bn_))
+                return
             r = dwconv_wgrad(xv, dv, Fr, H_, H_, C_, bn_, relu_, out=t)
             if t is None:
                 grads[n] = r
@@ -448,15 +461,27 @@ class StemFn(Function):
         M1, M2 = Fr * H1 * H1, Fr * H2 * H2
         du2 = bn_bwd(dOut, sv['u2'], sv['bn2'], 'bn2', M2, 64, stats=stats2)
         dz1 = torch.empty((M1, 32), dtype=dtype, device=du2.device)
+        dW2 = None
         if dtype == torch.bfloat16:
             du2 = du2.contiguous()
-            dW2 = torch.zeros((64, 288), dtype=torch.float32, device=du2.device)
-            slabs = torch.empty((L.istvt_conv2_wgrad_slabs(), 64 * 288), dtype=torch.float32, device=du2.device)
-            _lib.check(L.istvt_conv2_wgrad(du2.data_ptr(), sv['u1'].data_ptr(), sv['bn1'].ptr(), slabs.data_ptr(),
-                                           dW2.data_ptr(), Fr, H1, H1, _stream()), 'istvt_conv2_wgrad')
+            q2 = P['conv2.weight']
+
+            def conv2_wgrad(du=du2, u1=sv['u1'], bn1=sv['bn1']):
+                dW = torch.zeros((64, 288), dtype=torch.float32, device=du.device)
+                slabs = torch.empty((L.istvt_conv2_wgrad_slabs(), 64 * 288), dtype=torch.float32, device=du.device)
+                _lib.check(L.istvt_conv2_wgrad(du.data_ptr(), u1.data_ptr(), bn1.ptr(), slabs.data_ptr(), dW.data_ptr(),
+                                               Fr, H1, H1, _stream()), 'istvt_conv2_wgrad')
+                return dW.view(64, 3, 3, 32).permute(0, 3, 1, 2)
+            if side_on and getattr(q2, '_istvt_fused_grad', False) and q2.grad is not None:
+                # nothing later reads it: beside the input gradient, on the side stream, added into .grad there
+                from . import functional as Fn
+                Fn.side_launch(du2.device, lambda: q2.grad.add_(conv2_wgrad()), keep=(du2, sv['u1'], sv['bn1']))
+                grads['conv2.weight'] = None
+            else:
+                dW2 = conv2_wgrad().contiguous()
             _lib.check(L.istvt_conv2_dgrad(du2.data_ptr(), sv['w2'].data_ptr(), sv['u1'].data_ptr(), sv['bn1'].ptr(),
                                            dz1.data_ptr(), Fr, H1, H1, _stream()), 'istvt_conv2_dgrad')
-            del du2, slabs
+            del du2
         else:
             col2 = torch.empty((M2, 288), dtype=dtype, device=du2.device)
             _lib.check(L.istvt_im2col3x3(sv['u1'].data_ptr(), sv['bn1'].ptr(), 1, col2.data_ptr(), Fr, H1, H1, 32, dtc, _stream()),
@@ -468,7 +493,8 @@ class StemFn(Function):
                                          dtc, _stream()),
                        'istvt_col2im3x3')
             del dcol2
-        grads['conv2.weight'] = dW2.view(64, 3, 3, 32).permute(0, 3, 1, 2).contiguous()
+        if 'conv2.weight' not in grads:
+            grads['conv2.weight'] = dW2 if dtype == torch.bfloat16 else dW2.view(64, 3, 3, 32).permute(0, 3, 1, 2).contiguous()
         du1 = bn_bwd(dz1, sv['u1'], sv['bn1'], 'bn1', M1, 32)
         del dz1
         if dtype == torch.bfloat16 and H1 <= 128:
